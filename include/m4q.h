@@ -1,0 +1,175 @@
+/* m4q.h - C ABI of libm4q_hip.so: batched receding-horizon MPC for quantum state preparation on
+ * AMD MI355X (gfx950).  This is the drop-in boundary for the hot path of andgoldschmidt/MPC4quantum.
+ *
+ * The reference has no FFI: its boundary for this path is three Python call signatures
+ * (citations into the reference tree):
+ *     mpc4quantum/mpc.py:128-129       mpc(x0, dim_u, order, X_targ, U_targ, clock, experiment, model, Q, R, Qf, ...)
+ *     mpc4quantum/optimize.py:12       quad_program(x_init, X_bm, U_bm, Q_ls, R_ls, A_ls, B_ls, Delta_ls, u_prev, sat, du)
+ *     mpc4quantum/linearize.py:61-70   WrapModel.get_model_along_traj(xs, us, ts)
+ * and the plant call  mpc4quantum/experiment.py:202-212  QExperiment.simulate(x0, ts, us).
+ * Each entry point below names the reference interface it replaces.  mpc4quantum_amd/ binds them
+ * with ctypes; INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - complex numbers are interleaved (re, im) doubles; all arithmetic is fp64;
+ *   - every array is C-contiguous with the ENSEMBLE AXIS OUTERMOST and TIME before state:
+ *       trajectories  X[b][t][i]   (the reference holds one instance as X[i][t]);
+ *   - a model is the reference's DMDc.A block matrix, A[b][i][p*n + k], n x n(1+P) (model.py:95-103,
+ *     column layout of linearize.krtimes, linearize.py:80-89); P = number of non-constant control
+ *     monomials of the library of the given order (linearize.py:113-120);
+ *   - "*_per_instance" = 0 means one array shared by the whole ensemble (no leading b axis);
+ *   - host entry points (m4q_*_batch) take caller-owned HOST buffers, copy, launch, copy back;
+ *     the session API keeps everything resident in HBM;
+ *   - return value: 0 on success, a negative number on failure (-hipError_t for runtime errors,
+ *     M4Q_E_* otherwise); m4q_last_error() gives the message.  One host thread per session.
+ */
+#ifndef M4Q_H
+#define M4Q_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define M4Q_API __attribute__((visibility("default")))
+#else
+#define M4Q_API
+#endif
+
+#define M4Q_E_UNSUPPORTED (-1001) /* (dim_x, dim_u, order) has no compiled kernel */
+#define M4Q_E_BADARG (-1002)
+#define M4Q_E_NODEVICE (-1003)
+
+/* qp_flags */
+#define M4Q_QP_REF_LQR 1 /* reproduce mpc4quantum/lqr.py:14-79 as written (no Delta, no du band) */
+#define M4Q_QP_DU_BAND 2 /* also clip the first control to u_prev +- du (optimize.py:29-30) */
+
+/* plant_kind */
+#define M4Q_PLANT_NONE 0        /* caller supplies xs[step+1] between m4q_session_run calls */
+#define M4Q_PLANT_HAMILTONIAN 1 /* rho+ = U rho U^H, U = expm(-i dt (H0 + sum_k u_k H_k)), d x d operators */
+#define M4Q_PLANT_GENERATOR 2   /* x+ = expm(dt (L0 + sum_k u_k L_k)) x, n x n operators */
+
+/* exit codes per instance (mpc.py:130,195,202,291): 0 normal, 1 exit_condition (host side),
+ * 2 reserved (solver warning: cannot occur without OSQP), 3 non-finite objective */
+
+typedef struct m4q_problem {
+  int32_t dim_x;   /* n = d*d: 4, 9 or 16 */
+  int32_t dim_u;   /* m */
+  int32_t order;   /* control-library order (1 or 2) */
+  int32_t horizon; /* T (StepClock.horizon, mpc.py:17) */
+  int32_t n_steps; /* StepClock.n_steps (mpc.py:18) */
+  int32_t max_iter;   /* SQP iteration cap per MPC step (mpc.py:128, default 100) */
+  int32_t warm_start; /* mpc.py:208 */
+  int32_t qp_flags;
+  int32_t plant_kind;
+  int32_t model_per_instance;
+  int32_t plant_per_instance;
+  int32_t target_per_instance;
+  int32_t target_cols; /* columns of X_targ; U_targ has the same count (extra ones unused) */
+  int32_t reserved;
+  double dt;     /* StepClock.dt */
+  double sat;    /* |u| <= sat (optimize.py:43, lqr.py:76) */
+  double du;     /* first-control band (optimize.py:29-30); ignored without M4Q_QP_DU_BAND */
+  double ls_tol; /* SQP stop: ||alpha dZ|| < ls_tol (mpc.py:224, 1e-4) */
+} m4q_problem;
+
+M4Q_API const char* m4q_last_error(void);
+M4Q_API const char* m4q_version(void);
+/* number of HIP devices visible; < 0 on error */
+M4Q_API int m4q_device_count(void);
+/* 1 if a kernel exists for this shape */
+M4Q_API int m4q_supported(int32_t dim_x, int32_t dim_u, int32_t order);
+/* number of non-constant monomials P for (order, dim_u) (linearize.size_of_library - 1) */
+M4Q_API int m4q_library_size(int32_t order, int32_t dim_u);
+/* exponent table in the reference's order, out[(P+1)*dim_u] (linearize.create_power_list) */
+M4Q_API int m4q_power_list(int32_t order, int32_t dim_u, int32_t* out);
+
+/* ---- fine-grained host entry points --------------------------------------------------------- */
+
+/* replaces WrapModel.get_model_along_traj (linearize.py:61-70) for B trajectories.
+ * models [B|1][n][n(1+P)] c, X [B][T][n] c (the T linearisation points), U [B][T][m] r
+ * -> A_ls [B][T][n][n] c, B_ls [B][T][n][m] c, Delta_ls [B][T][n] c */
+M4Q_API int m4q_linearize_batch(int32_t B, int32_t dim_x, int32_t dim_u, int32_t order, int32_t T, const double* models,
+                        int32_t model_per_instance, const double* X, const double* U, double* A_ls, double* B_ls,
+                        double* Delta_ls);
+
+/* replaces quad_program (optimize.py:12-60 statement; lqr.py:14-79 arithmetic) for B problems.
+ * x_init [B][n] c, X_bm [B|1][T+1][n] c, U_bm [B|1][T][m] r, Q_ls [T+1][n][n] c, R_ls [T][m][m] c,
+ * A_ls [B][T][n][n] c, B_ls [B][T][n][m] c, Delta_ls [B][T][n] c (NULL = zero),
+ * u_prev [B][m] r (NULL = no band) -> X_opt [B][T+1][n] c, U_opt [B][T][m] r, cost [B] r,
+ * gains [B][T][n+1][m] c (NULL to skip; gains[b][t][col][k] = Gains[t][k][col] of lqr.py:61) */
+M4Q_API int m4q_quad_program_batch(int32_t B, int32_t dim_x, int32_t dim_u, int32_t T, int32_t qp_flags, double sat, double du,
+                           const double* x_init, const double* X_bm, const double* U_bm, int32_t bm_per_instance,
+                           const double* Q_ls, const double* R_ls, const double* A_ls, const double* B_ls,
+                           const double* Delta_ls, const double* u_prev, double* X_opt, double* U_opt, double* cost,
+                           double* gains);
+
+/* replaces QExperiment.simulate over one held-control step (experiment.py:202-212, mpc.py:256-260).
+ * x [B][n] c, u [B][m] r, op0 [B|1][k][k] c, ops [B|1][m][k][k] c with k = d (HAMILTONIAN) or n (GENERATOR)
+ * -> x_next [B][n] c */
+M4Q_API int m4q_plant_step_batch(int32_t B, int32_t dim_x, int32_t dim_u, int32_t plant_kind, double dt, const double* x,
+                         const double* u, const double* op0, const double* ops, int32_t plant_per_instance,
+                         double* x_next);
+
+/* replaces the whole mpc() loop body (mpc.py:161-292) for B closed loops, all n_steps in one launch.
+ * models [B|1][n][n(1+P)] c, x0 [B][n] c, X_targ [B|1][cols][n] c, U_targ [B|1][cols][m] r,
+ * Q, Qf [n][n] c, R [m][m] c, op0/ops as in m4q_plant_step_batch
+ * -> xs [B][n_steps+1][n] c, us [B][n_steps][m] r, exit_codes [B], steps_done [B], qp_solves [B][n_steps] */
+M4Q_API int m4q_mpc_batch(const m4q_problem* p, int32_t B, const double* models, const double* x0, const double* X_targ,
+                  const double* U_targ, const double* Q, const double* R, const double* Qf, const double* op0,
+                  const double* ops, double* xs, double* us, int32_t* exit_codes, int32_t* steps_done,
+                  int32_t* qp_solves);
+
+/* ---- resident session (inputs stay in HBM; used by bench.py and by step-wise host plants) ---- */
+typedef struct m4q_session m4q_session;
+
+enum m4q_field {
+  M4Q_F_MODELS = 0,
+  M4Q_F_X0 = 1,
+  M4Q_F_X_TARG = 2,
+  M4Q_F_U_TARG = 3,
+  M4Q_F_Q = 4,
+  M4Q_F_R = 5,
+  M4Q_F_QF = 6,
+  M4Q_F_OP0 = 7,
+  M4Q_F_OPS = 8,
+  M4Q_F_XS = 9,         /* [B][n_steps+1][n] c */
+  M4Q_F_US = 10,        /* [B][n_steps][m] r */
+  M4Q_F_CODES = 11,     /* [B] i32 */
+  M4Q_F_STEPS_DONE = 12,/* [B] i32 */
+  M4Q_F_QP_SOLVES = 13, /* [B][n_steps] i32 */
+  M4Q_F_COUNT = 14
+};
+
+/* device < 0: keep the current device */
+M4Q_API int m4q_session_create(const m4q_problem* p, int32_t B, int32_t device, m4q_session** out);
+M4Q_API void m4q_session_destroy(m4q_session* s);
+/* size in bytes the session expects for a field */
+M4Q_API size_t m4q_session_field_bytes(const m4q_session* s, int32_t field);
+/* host -> device / device -> host copy of a whole field (synchronous w.r.t. the session stream) */
+M4Q_API int m4q_session_upload(m4q_session* s, int32_t field, const void* host, size_t bytes);
+M4Q_API int m4q_session_download(m4q_session* s, int32_t field, void* host, size_t bytes);
+/* upload/download one MPC step's column of XS for every instance: host [B][n] c (host plants) */
+M4Q_API int m4q_session_put_state(m4q_session* s, int32_t step, const void* host);
+M4Q_API int m4q_session_get_state(m4q_session* s, int32_t step, void* host);
+/* raw device pointer of a field (for collectives on the results); NULL if unknown */
+M4Q_API void* m4q_session_device_ptr(m4q_session* s, int32_t field);
+/* use caller-owned DEVICE memory for an output field (XS, US, CODES, STEPS_DONE, QP_SOLVES) */
+M4Q_API int m4q_session_bind_output(m4q_session* s, int32_t field, void* device_ptr, size_t bytes);
+/* enqueue MPC steps [step_begin, step_end) on the session stream; step_begin == 0 re-initialises the guesses */
+M4Q_API int m4q_session_run(m4q_session* s, int32_t step_begin, int32_t step_end);
+M4Q_API int m4q_session_sync(m4q_session* s);
+/* mark instances finished from the host (exit_condition, mpc.py:289-292): codes [B] i32, nonzero = stop */
+M4Q_API int m4q_session_set_codes(m4q_session* s, const int32_t* codes);
+/* kernel time of the launches since the last call, from HIP events on the session stream */
+M4Q_API int m4q_session_kernel_ms(m4q_session* s, double* total_ms, int32_t* launches);
+/* resident bytes and launch geometry, for reports */
+M4Q_API int m4q_session_info(const m4q_session* s, int64_t* hbm_bytes, int32_t* grid, int32_t* lds_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M4Q_H */

@@ -1,0 +1,73 @@
+"""Build libm4q_hip.so for gfx950: one object per problem shape (m4q_kernels.hip with
+-DM4Q_NX/-DM4Q_NU/-DM4Q_ORDER), one for the C ABI, linked in-tree next to the Python package.
+
+    python mpc4quantum_amd/csrc/build.py [--force] [--jobs N] [--shfl]
+"""
+import argparse
+import os
+import re
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+OBJ = os.path.join(HERE, "build")
+LIB = os.path.join(PKG, "libm4q_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-command-line-argument"]
+HEADERS = ["m4q_device.h", "m4q_mpc.h", "m4q_args.h", "m4q_shapes.inc", os.path.join("..", "..", "include", "m4q.h")]
+
+
+def shapes():
+    txt = open(os.path.join(HERE, "m4q_shapes.inc")).read()
+    return [tuple(int(v) for v in m) for m in re.findall(r"^M4Q_SHAPE\((\d+),\s*(\d+),\s*(\d+)\)", txt, re.M)]
+
+
+def stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def run(cmd):
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        sys.stderr.write(" ".join(cmd) + "\n" + res.stdout)
+        raise RuntimeError("hipcc failed")
+    return res.stdout
+
+
+def build(force=False, jobs=None, extra=()):
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = [os.path.join(HERE, h) for h in HEADERS]
+    jobs_list = []
+    objs = []
+    for nx, nu, order in shapes():
+        obj = os.path.join(OBJ, "kernels_%d_%d_%d.o" % (nx, nu, order))
+        objs.append(obj)
+        src = os.path.join(HERE, "m4q_kernels.hip")
+        if force or stale(obj, [src] + hdrs):
+            jobs_list.append([HIPCC] + COMMON + list(extra) + ["-DM4Q_NX=%d" % nx, "-DM4Q_NU=%d" % nu,
+                                                                "-DM4Q_ORDER=%d" % order, "-c", src, "-o", obj])
+    capi = os.path.join(OBJ, "capi.o")
+    objs.append(capi)
+    src = os.path.join(HERE, "m4q_capi.hip")
+    if force or stale(capi, [src] + hdrs):
+        jobs_list.append([HIPCC] + COMMON + ["-c", src, "-o", capi])
+    if jobs_list:
+        with ThreadPoolExecutor(max_workers=jobs or min(6, os.cpu_count() or 2)) as ex:
+            list(ex.map(run, jobs_list))
+    if force or jobs_list or stale(LIB, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--jobs", type=int, default=None)
+    ap.add_argument("--shfl", action="store_true", help="debug build: row broadcasts through ds_bpermute instead of DPP")
+    a = ap.parse_args()
+    print(build(a.force, a.jobs, ["-DM4Q_BCAST_SHFL"] if a.shfl else []))

@@ -1,0 +1,67 @@
+// m4q_args.h - plain argument blocks passed by value to the kernels, shared by the per-shape
+// kernel translation units (m4q_kernels.hip) and the host side of the C ABI (m4q_capi.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace m4q {
+
+struct cplx;
+
+struct MpcArgs {
+  int B, T, n_steps, max_iter, warm_start, flags, step_begin, step_end;
+  double dt, sat, du, ls_tol;
+  const cplx* models;  long model_stride;   // [B|1][n][n(1+P)]
+  const cplx* x0;                           // [B][n]
+  const cplx* x_targ;  long xt_stride;      // [B|1][cols][n]
+  const double* u_targ; long ut_stride;     // [B|1][cols][m]
+  const cplx* Q; const cplx* Qf; const cplx* R;
+  const double* Cq; const double* Cqf; const double* Cr;   // line-search blocks (mpc.py:103-116)
+  const cplx* op0; long op0_stride;         // plant operators
+  const cplx* ops; long ops_stride;
+  cplx* xs; double* us; int* codes; int* steps_done; int* qp_solves;
+  cplx* Xg; double* Ug;                     // per-instance SQP guess  [B][T+1][n], [B][T][m]
+  cplx* ws_Xo; double* ws_Uo; cplx* ws_gains;   // per resident row: [grid*4][T+1][n], [..][T][m], [..][T][n+1][m]
+};
+
+struct LinArgs {
+  int B, T;
+  const cplx* models; long model_stride;
+  const cplx* X; const double* U;           // [B][T][n], [B][T][m]
+  cplx* A_ls; cplx* B_ls; cplx* D_ls;
+};
+
+struct QpArgs {
+  int B, T, flags;
+  double sat, du;
+  const cplx* x_init;
+  const cplx* X_bm; long xbm_stride;
+  const double* U_bm; long ubm_stride;
+  const cplx* Q_ls; const cplx* R_ls;       // [T+1][n][n], [T][m][m]
+  const cplx* A_ls; const cplx* B_ls; const cplx* D_ls;
+  const double* u_prev;
+  cplx* X_opt; double* U_opt; double* cost; cplx* gains;   // gains: caller buffer or workspace [B][T][n+1][m]
+};
+
+struct PlantArgs {
+  int B, kind;
+  double dt;
+  const cplx* x; const double* u;
+  const cplx* op0; long op0_stride;
+  const cplx* ops; long ops_stride;
+  cplx* x_next;
+};
+
+// one entry per compiled (dim_x, dim_u, order)
+struct ShapeOps {
+  int nx, nu, order, np, d;
+  size_t (*mpc_lds_bytes)();
+  int (*launch_mpc)(const MpcArgs&, int plant_kind, int grid, hipStream_t);
+  int (*launch_linearize)(const LinArgs&, hipStream_t);
+  int (*launch_qp)(const QpArgs&, hipStream_t);
+  int (*launch_plant)(const PlantArgs&, hipStream_t);
+  int (*power_list)(int32_t* out);
+  int (*occupancy)(int plant_kind);         // resident workgroups per CU of the fused kernel
+};
+
+}  // namespace m4q

@@ -1,0 +1,550 @@
+// m4q_capi.hip - host side of the C ABI declared in include/m4q.h.
+// Owns device memory, streams and events; dispatches to the per-shape kernel objects.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/m4q.h"
+#include "m4q_args.h"
+
+namespace m4q {
+struct cplx { double re, im; };
+}
+using m4q::cplx;
+
+// per-shape registration functions (m4q_kernels.hip compiled once per shape)
+#define M4Q_SHAPE(nx, nu, ord) extern "C" const m4q::ShapeOps* m4q_shape_##nx##_##nu##_##ord();
+#include "m4q_shapes.inc"
+#undef M4Q_SHAPE
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) return fail(-(int)e_, "%s: %s", #expr, hipGetErrorString(e_));       \
+  } while (0)
+
+const m4q::ShapeOps* find_shape(int nx, int nu, int order) {
+  static const m4q::ShapeOps* table[] = {
+#define M4Q_SHAPE(nx, nu, ord) m4q_shape_##nx##_##nu##_##ord(),
+#include "m4q_shapes.inc"
+#undef M4Q_SHAPE
+  };
+  for (const m4q::ShapeOps* s : table)
+    if (s->nx == nx && s->nu == nu && s->order == order) return s;
+  return nullptr;
+}
+
+// any compiled order for (nx, nu): the QP and plant kernels do not depend on the library order
+const m4q::ShapeOps* find_shape_any_order(int nx, int nu) {
+  for (int ord = 1; ord <= 3; ++ord)
+    if (const m4q::ShapeOps* s = find_shape(nx, nu, ord)) return s;
+  return nullptr;
+}
+
+int dim_d(int nx) { return nx == 4 ? 2 : nx == 9 ? 3 : nx == 16 ? 4 : 0; }
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  bool owned = true;
+  int alloc(size_t n) {
+    release();
+    bytes = n;
+    owned = true;
+    if (n == 0) return 0;
+    hipError_t e = hipMalloc(&p, n);
+    if (e != hipSuccess) { p = nullptr; return fail(-(int)e, "hipMalloc(%zu): %s", n, hipGetErrorString(e)); }
+    return 0;
+  }
+  void release() {
+    if (p && owned) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  ~DevBuf() { release(); }
+};
+
+// symmetrised real-ified cost block of iqp_line_search (mpc.py:92-93,103-104,112-116)
+void ls_block(const double* M, int k, std::vector<double>& out) {
+  const int s = 2 * k;
+  std::vector<double> c((size_t)s * s);
+  for (int i = 0; i < k; ++i)
+    for (int j = 0; j < k; ++j) {
+      const double re = M[2 * (i * k + j)], im = M[2 * (i * k + j) + 1];
+      c[(size_t)i * s + j] = re;
+      c[(size_t)i * s + (j + k)] = -im;
+      c[(size_t)(i + k) * s + j] = im;
+      c[(size_t)(i + k) * s + (j + k)] = re;
+    }
+  out.resize((size_t)s * s);
+  for (int i = 0; i < s; ++i)
+    for (int j = 0; j < s; ++j) out[(size_t)i * s + j] = 0.5 * (c[(size_t)i * s + j] + c[(size_t)j * s + i]);
+}
+
+}  // namespace
+
+struct m4q_session {
+  m4q_problem prob{};
+  int B = 0;
+  int device = 0;
+  const m4q::ShapeOps* shape = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int grid = 1;
+  DevBuf f[M4Q_F_COUNT];
+  DevBuf Cq, Cqf, Cr, Xg, Ug, wsXo, wsUo, wsG;
+  size_t fbytes[M4Q_F_COUNT]{};
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  double ms_total = 0.0;
+  int launches = 0;
+  bool costs_dirty = true;
+  std::vector<double> hQ, hQf, hR;
+};
+
+extern "C" {
+
+const char* m4q_last_error(void) { return g_err.c_str(); }
+const char* m4q_version(void) { return "m4q-hip 0.1 (gfx950)"; }
+
+int m4q_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return fail(-(int)e, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  return n;
+}
+
+int m4q_supported(int32_t dim_x, int32_t dim_u, int32_t order) { return find_shape(dim_x, dim_u, order) ? 1 : 0; }
+
+int m4q_library_size(int32_t order, int32_t dim_u) {
+  if (order < 0 || dim_u < 1) return fail(M4Q_E_BADARG, "bad (order, dim_u)");
+  // C(order + m, m) - 1
+  long r = 1;
+  for (int i = 1; i <= dim_u; ++i) r = r * (order + i) / i;
+  return (int)r - 1;
+}
+
+int m4q_power_list(int32_t order, int32_t dim_u, int32_t* out) {
+  for (int nx : {4, 9, 16})
+    if (const m4q::ShapeOps* s = find_shape(nx, dim_u, order)) return s->power_list(out);
+  return fail(M4Q_E_UNSUPPORTED, "no compiled kernel with (order=%d, dim_u=%d)", order, dim_u);
+}
+
+// ------------------------------------------------------------------------------------------
+// session
+// ------------------------------------------------------------------------------------------
+int m4q_session_create(const m4q_problem* p, int32_t B, int32_t device, m4q_session** out) {
+  if (!p || !out || B <= 0) return fail(M4Q_E_BADARG, "m4q_session_create: bad argument");
+  const m4q::ShapeOps* sh = find_shape(p->dim_x, p->dim_u, p->order);
+  if (!sh) return fail(M4Q_E_UNSUPPORTED, "no kernel for dim_x=%d dim_u=%d order=%d", p->dim_x, p->dim_u, p->order);
+  if (p->horizon < 1 || p->n_steps < 1 || p->target_cols < p->horizon + 1 + (p->n_steps > 1 ? p->n_steps - 2 : 0))
+    return fail(M4Q_E_BADARG, "horizon/n_steps/target_cols inconsistent (need target_cols >= n_steps + horizon - 1)");
+  if (!(p->sat > 0)) return fail(M4Q_E_BADARG, "sat must be positive (the reference crashes on sat=None, mpc.py Q5)");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) return fail(M4Q_E_NODEVICE, "no HIP device: %s", hipGetErrorString(e));
+  if (device >= 0) HIP_TRY(hipSetDevice(device));
+  m4q_session* s = new m4q_session();
+  s->prob = *p;
+  s->B = B;
+  s->shape = sh;
+  HIP_TRY(hipGetDevice(&s->device));
+  HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&s->ev0));
+  HIP_TRY(hipEventCreate(&s->ev1));
+  const size_t n = p->dim_x, m = p->dim_u, P = sh->np, T = p->horizon, ns = p->n_steps, cols = p->target_cols;
+  const size_t k = p->plant_kind == M4Q_PLANT_GENERATOR ? n : (size_t)sh->d;
+  const size_t C = 16;
+  size_t* fb = s->fbytes;
+  fb[M4Q_F_MODELS] = (p->model_per_instance ? B : 1) * n * n * (1 + P) * C;
+  fb[M4Q_F_X0] = (size_t)B * n * C;
+  fb[M4Q_F_X_TARG] = (p->target_per_instance ? B : 1) * cols * n * C;
+  fb[M4Q_F_U_TARG] = (p->target_per_instance ? B : 1) * cols * m * 8;
+  fb[M4Q_F_Q] = n * n * C;
+  fb[M4Q_F_QF] = n * n * C;
+  fb[M4Q_F_R] = m * m * C;
+  fb[M4Q_F_OP0] = p->plant_kind == M4Q_PLANT_NONE ? 0 : (p->plant_per_instance ? B : 1) * k * k * C;
+  fb[M4Q_F_OPS] = p->plant_kind == M4Q_PLANT_NONE ? 0 : (p->plant_per_instance ? B : 1) * m * k * k * C;
+  fb[M4Q_F_XS] = (size_t)B * (ns + 1) * n * C;
+  fb[M4Q_F_US] = (size_t)B * ns * m * 8;
+  fb[M4Q_F_CODES] = (size_t)B * 4;
+  fb[M4Q_F_STEPS_DONE] = (size_t)B * 4;
+  fb[M4Q_F_QP_SOLVES] = (size_t)B * ns * 4;
+  int rc = 0;
+  for (int i = 0; i < M4Q_F_COUNT && !rc; ++i) rc = s->f[i].alloc(fb[i]);
+  // resident grid: as many workgroups as the device holds at once (persistent, quad-strided)
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, s->device));
+  int per_cu = sh->occupancy(p->plant_kind);
+  if (per_cu < 1) per_cu = 1;
+  const int nquads = (B + 3) / 4;
+  long resident = (long)per_cu * prop.multiProcessorCount;
+  s->grid = (int)(nquads < resident ? nquads : resident);
+  const size_t rows = (size_t)s->grid * 4;
+  if (!rc) rc = s->Xg.alloc((size_t)B * (T + 1) * n * C);
+  if (!rc) rc = s->Ug.alloc((size_t)B * T * m * 8);
+  if (!rc) rc = s->wsXo.alloc(rows * (T + 1) * n * C);
+  if (!rc) rc = s->wsUo.alloc(rows * T * m * 8);
+  if (!rc) rc = s->wsG.alloc(rows * T * (n + 1) * m * C);
+  if (!rc) rc = s->Cq.alloc(4 * n * n * 8);
+  if (!rc) rc = s->Cqf.alloc(4 * n * n * 8);
+  if (!rc) rc = s->Cr.alloc(4 * m * m * 8);
+  if (rc) { m4q_session_destroy(s); return rc; }
+  for (int i : {M4Q_F_XS, M4Q_F_US, M4Q_F_CODES, M4Q_F_STEPS_DONE, M4Q_F_QP_SOLVES})
+    HIP_TRY(hipMemsetAsync(s->f[i].p, 0, fb[i], s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  *out = s;
+  return 0;
+}
+
+void m4q_session_destroy(m4q_session* s) {
+  if (!s) return;
+  for (auto& pr : s->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  if (s->ev0) (void)hipEventDestroy(s->ev0);
+  if (s->ev1) (void)hipEventDestroy(s->ev1);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+}
+
+size_t m4q_session_field_bytes(const m4q_session* s, int32_t field) {
+  if (!s || field < 0 || field >= M4Q_F_COUNT) return 0;
+  return s->fbytes[field];
+}
+
+int m4q_session_upload(m4q_session* s, int32_t field, const void* host, size_t bytes) {
+  if (!s || field < 0 || field >= M4Q_F_COUNT || !host) return fail(M4Q_E_BADARG, "m4q_session_upload: bad argument");
+  if (bytes != s->fbytes[field]) return fail(M4Q_E_BADARG, "field %d expects %zu bytes, got %zu", field, s->fbytes[field], bytes);
+  if (bytes == 0) return 0;
+  HIP_TRY(hipMemcpyAsync(s->f[field].p, host, bytes, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  const size_t n = s->prob.dim_x, m = s->prob.dim_u;
+  if (field == M4Q_F_Q) { s->hQ.assign((const double*)host, (const double*)host + 2 * n * n); s->costs_dirty = true; }
+  if (field == M4Q_F_QF) { s->hQf.assign((const double*)host, (const double*)host + 2 * n * n); s->costs_dirty = true; }
+  if (field == M4Q_F_R) { s->hR.assign((const double*)host, (const double*)host + 2 * m * m); s->costs_dirty = true; }
+  return 0;
+}
+
+int m4q_session_download(m4q_session* s, int32_t field, void* host, size_t bytes) {
+  if (!s || field < 0 || field >= M4Q_F_COUNT || !host) return fail(M4Q_E_BADARG, "m4q_session_download: bad argument");
+  if (bytes != s->fbytes[field]) return fail(M4Q_E_BADARG, "field %d holds %zu bytes, asked %zu", field, s->fbytes[field], bytes);
+  if (bytes == 0) return 0;
+  HIP_TRY(hipMemcpyAsync(host, s->f[field].p, bytes, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return 0;
+}
+
+int m4q_session_put_state(m4q_session* s, int32_t step, const void* host) {
+  if (!s || !host || step < 0 || step > s->prob.n_steps) return fail(M4Q_E_BADARG, "m4q_session_put_state: bad argument");
+  const size_t row = (size_t)s->prob.dim_x * 16;
+  HIP_TRY(hipMemcpy2DAsync((char*)s->f[M4Q_F_XS].p + (size_t)step * row, (size_t)(s->prob.n_steps + 1) * row, host, row, row,
+                           s->B, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return 0;
+}
+
+int m4q_session_get_state(m4q_session* s, int32_t step, void* host) {
+  if (!s || !host || step < 0 || step > s->prob.n_steps) return fail(M4Q_E_BADARG, "m4q_session_get_state: bad argument");
+  const size_t row = (size_t)s->prob.dim_x * 16;
+  HIP_TRY(hipMemcpy2DAsync(host, row, (const char*)s->f[M4Q_F_XS].p + (size_t)step * row, (size_t)(s->prob.n_steps + 1) * row,
+                           row, s->B, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return 0;
+}
+
+void* m4q_session_device_ptr(m4q_session* s, int32_t field) {
+  if (!s || field < 0 || field >= M4Q_F_COUNT) return nullptr;
+  return s->f[field].p;
+}
+
+int m4q_session_bind_output(m4q_session* s, int32_t field, void* device_ptr, size_t bytes) {
+  if (!s || !device_ptr || field < M4Q_F_XS || field >= M4Q_F_COUNT) return fail(M4Q_E_BADARG, "m4q_session_bind_output: bad field");
+  if (bytes != s->fbytes[field]) return fail(M4Q_E_BADARG, "field %d expects %zu bytes, got %zu", field, s->fbytes[field], bytes);
+  s->f[field].release();
+  s->f[field].p = device_ptr;
+  s->f[field].bytes = bytes;
+  s->f[field].owned = false;
+  return 0;
+}
+
+static int refresh_costs(m4q_session* s) {
+  if (!s->costs_dirty) return 0;
+  const int n = s->prob.dim_x, m = s->prob.dim_u;
+  if (s->hQ.empty() || s->hQf.empty() || s->hR.empty()) return fail(M4Q_E_BADARG, "Q, Qf and R must be uploaded before running");
+  std::vector<double> c;
+  ls_block(s->hQ.data(), n, c);
+  HIP_TRY(hipMemcpy(s->Cq.p, c.data(), c.size() * 8, hipMemcpyHostToDevice));
+  ls_block(s->hQf.data(), n, c);
+  HIP_TRY(hipMemcpy(s->Cqf.p, c.data(), c.size() * 8, hipMemcpyHostToDevice));
+  ls_block(s->hR.data(), m, c);
+  HIP_TRY(hipMemcpy(s->Cr.p, c.data(), c.size() * 8, hipMemcpyHostToDevice));
+  s->costs_dirty = false;
+  return 0;
+}
+
+int m4q_session_run(m4q_session* s, int32_t step_begin, int32_t step_end) {
+  if (!s || step_begin < 0 || step_end > s->prob.n_steps || step_begin >= step_end)
+    return fail(M4Q_E_BADARG, "m4q_session_run: bad step range [%d, %d)", step_begin, step_end);
+  int rc = refresh_costs(s);
+  if (rc) return rc;
+  const m4q_problem& p = s->prob;
+  const size_t n = p.dim_x, m = p.dim_u, P = s->shape->np;
+  const size_t k = p.plant_kind == M4Q_PLANT_GENERATOR ? n : (size_t)s->shape->d;
+  m4q::MpcArgs a{};
+  a.B = s->B; a.T = p.horizon; a.n_steps = p.n_steps; a.max_iter = p.max_iter; a.warm_start = p.warm_start;
+  a.flags = p.qp_flags; a.step_begin = step_begin; a.step_end = step_end;
+  a.dt = p.dt; a.sat = p.sat; a.du = p.du; a.ls_tol = p.ls_tol;
+  a.models = (const cplx*)s->f[M4Q_F_MODELS].p; a.model_stride = p.model_per_instance ? (long)(n * n * (1 + P)) : 0;
+  a.x0 = (const cplx*)s->f[M4Q_F_X0].p;
+  a.x_targ = (const cplx*)s->f[M4Q_F_X_TARG].p; a.xt_stride = p.target_per_instance ? (long)(p.target_cols * n) : 0;
+  a.u_targ = (const double*)s->f[M4Q_F_U_TARG].p; a.ut_stride = p.target_per_instance ? (long)(p.target_cols * m) : 0;
+  a.Q = (const cplx*)s->f[M4Q_F_Q].p; a.Qf = (const cplx*)s->f[M4Q_F_QF].p; a.R = (const cplx*)s->f[M4Q_F_R].p;
+  a.Cq = (const double*)s->Cq.p; a.Cqf = (const double*)s->Cqf.p; a.Cr = (const double*)s->Cr.p;
+  a.op0 = (const cplx*)s->f[M4Q_F_OP0].p; a.op0_stride = p.plant_per_instance ? (long)(k * k) : 0;
+  a.ops = (const cplx*)s->f[M4Q_F_OPS].p; a.ops_stride = p.plant_per_instance ? (long)(m * k * k) : 0;
+  if (p.plant_kind == M4Q_PLANT_NONE) { a.op0 = a.Q; a.ops = a.Q; a.op0_stride = a.ops_stride = 0; }
+  a.xs = (cplx*)s->f[M4Q_F_XS].p; a.us = (double*)s->f[M4Q_F_US].p;
+  a.codes = (int*)s->f[M4Q_F_CODES].p; a.steps_done = (int*)s->f[M4Q_F_STEPS_DONE].p; a.qp_solves = (int*)s->f[M4Q_F_QP_SOLVES].p;
+  a.Xg = (cplx*)s->Xg.p; a.Ug = (double*)s->Ug.p;
+  a.ws_Xo = (cplx*)s->wsXo.p; a.ws_Uo = (double*)s->wsUo.p; a.ws_gains = (cplx*)s->wsG.p;
+  if (step_begin == 0) {
+    HIP_TRY(hipMemsetAsync(s->f[M4Q_F_QP_SOLVES].p, 0, s->fbytes[M4Q_F_QP_SOLVES], s->stream));
+    HIP_TRY(hipMemsetAsync(s->f[M4Q_F_CODES].p, 0, s->fbytes[M4Q_F_CODES], s->stream));
+    HIP_TRY(hipMemsetAsync(s->f[M4Q_F_STEPS_DONE].p, 0, s->fbytes[M4Q_F_STEPS_DONE], s->stream));
+  }
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipEventRecord(e0, s->stream));
+  rc = s->shape->launch_mpc(a, p.plant_kind, s->grid, s->stream);
+  if (rc) return fail(rc, "mpc kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));
+  HIP_TRY(hipEventRecord(e1, s->stream));
+  s->pending.emplace_back(e0, e1);
+  return 0;
+}
+
+int m4q_session_sync(m4q_session* s) {
+  if (!s) return fail(M4Q_E_BADARG, "m4q_session_sync: null session");
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return 0;
+}
+
+int m4q_session_set_codes(m4q_session* s, const int32_t* codes) {
+  if (!s || !codes) return fail(M4Q_E_BADARG, "m4q_session_set_codes: bad argument");
+  HIP_TRY(hipMemcpyAsync(s->f[M4Q_F_CODES].p, codes, (size_t)s->B * 4, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return 0;
+}
+
+int m4q_session_kernel_ms(m4q_session* s, double* total_ms, int32_t* launches) {
+  if (!s) return fail(M4Q_E_BADARG, "m4q_session_kernel_ms: null session");
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  double tot = 0.0;
+  int n = 0;
+  for (auto& pr : s->pending) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+    tot += ms;
+    ++n;
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  s->pending.clear();
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = n;
+  return 0;
+}
+
+int m4q_session_info(const m4q_session* s, int64_t* hbm_bytes, int32_t* grid, int32_t* lds_bytes) {
+  if (!s) return fail(M4Q_E_BADARG, "m4q_session_info: null session");
+  int64_t tot = 0;
+  for (int i = 0; i < M4Q_F_COUNT; ++i) tot += (int64_t)s->f[i].bytes;
+  tot += (int64_t)(s->Xg.bytes + s->Ug.bytes + s->wsXo.bytes + s->wsUo.bytes + s->wsG.bytes);
+  if (hbm_bytes) *hbm_bytes = tot;
+  if (grid) *grid = s->grid;
+  if (lds_bytes) *lds_bytes = (int32_t)s->shape->mpc_lds_bytes();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// one-shot host entry points
+// ------------------------------------------------------------------------------------------
+namespace {
+struct Tmp {
+  std::vector<DevBuf*> bufs;
+  ~Tmp() { for (DevBuf* b : bufs) delete b; }
+  int up(const void* host, size_t bytes, void** out) {
+    DevBuf* b = new DevBuf();
+    bufs.push_back(b);
+    int rc = b->alloc(bytes);
+    if (rc) return rc;
+    if (host && bytes) {
+      hipError_t e = hipMemcpy(b->p, host, bytes, hipMemcpyHostToDevice);
+      if (e != hipSuccess) return fail(-(int)e, "hipMemcpy H2D: %s", hipGetErrorString(e));
+    }
+    *out = b->p;
+    return 0;
+  }
+};
+int down(void* host, const void* dev, size_t bytes) {
+  if (!host || !bytes) return 0;
+  hipError_t e = hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return fail(-(int)e, "hipMemcpy D2H: %s", hipGetErrorString(e));
+  return 0;
+}
+int need_device() {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0) return fail(M4Q_E_NODEVICE, "no HIP device: %s", hipGetErrorString(e));
+  return 0;
+}
+}  // namespace
+
+int m4q_linearize_batch(int32_t B, int32_t dim_x, int32_t dim_u, int32_t order, int32_t T, const double* models,
+                        int32_t model_per_instance, const double* X, const double* U, double* A_ls, double* B_ls,
+                        double* Delta_ls) {
+  const m4q::ShapeOps* sh = find_shape(dim_x, dim_u, order);
+  if (!sh) return fail(M4Q_E_UNSUPPORTED, "no kernel for dim_x=%d dim_u=%d order=%d", dim_x, dim_u, order);
+  if (B <= 0 || T <= 0 || !models || !X || !U || !A_ls || !B_ls || !Delta_ls) return fail(M4Q_E_BADARG, "m4q_linearize_batch: bad argument");
+  int rc = need_device();
+  if (rc) return rc;
+  const size_t n = dim_x, m = dim_u, P = sh->np, C = 16;
+  Tmp t;
+  m4q::LinArgs a{};
+  a.B = B; a.T = T;
+  a.model_stride = model_per_instance ? (long)(n * n * (1 + P)) : 0;
+  void *d_models, *d_X, *d_U, *d_A, *d_B, *d_D;
+  if ((rc = t.up(models, (model_per_instance ? B : 1) * n * n * (1 + P) * C, &d_models))) return rc;
+  if ((rc = t.up(X, (size_t)B * T * n * C, &d_X))) return rc;
+  if ((rc = t.up(U, (size_t)B * T * m * 8, &d_U))) return rc;
+  if ((rc = t.up(nullptr, (size_t)B * T * n * n * C, &d_A))) return rc;
+  if ((rc = t.up(nullptr, (size_t)B * T * n * m * C, &d_B))) return rc;
+  if ((rc = t.up(nullptr, (size_t)B * T * n * C, &d_D))) return rc;
+  a.models = (const cplx*)d_models; a.X = (const cplx*)d_X; a.U = (const double*)d_U;
+  a.A_ls = (cplx*)d_A; a.B_ls = (cplx*)d_B; a.D_ls = (cplx*)d_D;
+  rc = sh->launch_linearize(a, nullptr);
+  if (rc) return fail(rc, "linearize launch failed");
+  HIP_TRY(hipDeviceSynchronize());
+  if ((rc = down(A_ls, d_A, (size_t)B * T * n * n * C))) return rc;
+  if ((rc = down(B_ls, d_B, (size_t)B * T * n * m * C))) return rc;
+  return down(Delta_ls, d_D, (size_t)B * T * n * C);
+}
+
+int m4q_quad_program_batch(int32_t B, int32_t dim_x, int32_t dim_u, int32_t T, int32_t qp_flags, double sat, double du,
+                           const double* x_init, const double* X_bm, const double* U_bm, int32_t bm_per_instance,
+                           const double* Q_ls, const double* R_ls, const double* A_ls, const double* B_ls,
+                           const double* Delta_ls, const double* u_prev, double* X_opt, double* U_opt, double* cost,
+                           double* gains) {
+  const m4q::ShapeOps* sh = find_shape_any_order(dim_x, dim_u);
+  if (!sh) return fail(M4Q_E_UNSUPPORTED, "no kernel for dim_x=%d dim_u=%d", dim_x, dim_u);
+  if (B <= 0 || T <= 0 || !x_init || !X_bm || !U_bm || !Q_ls || !R_ls || !A_ls || !B_ls || !X_opt || !U_opt || !cost)
+    return fail(M4Q_E_BADARG, "m4q_quad_program_batch: bad argument");
+  if (!(sat > 0)) return fail(M4Q_E_BADARG, "sat must be positive");
+  int rc = need_device();
+  if (rc) return rc;
+  const size_t n = dim_x, m = dim_u, C = 16;
+  Tmp t;
+  m4q::QpArgs a{};
+  a.B = B; a.T = T; a.flags = qp_flags; a.sat = sat; a.du = du;
+  void *d_x, *d_xb, *d_ub, *d_q, *d_r, *d_a, *d_b, *d_d = nullptr, *d_up = nullptr, *d_xo, *d_uo, *d_c, *d_g;
+  if ((rc = t.up(x_init, (size_t)B * n * C, &d_x))) return rc;
+  if ((rc = t.up(X_bm, (bm_per_instance ? B : 1) * (size_t)(T + 1) * n * C, &d_xb))) return rc;
+  if ((rc = t.up(U_bm, (bm_per_instance ? B : 1) * (size_t)T * m * 8, &d_ub))) return rc;
+  if ((rc = t.up(Q_ls, (size_t)(T + 1) * n * n * C, &d_q))) return rc;
+  if ((rc = t.up(R_ls, (size_t)T * m * m * C, &d_r))) return rc;
+  if ((rc = t.up(A_ls, (size_t)B * T * n * n * C, &d_a))) return rc;
+  if ((rc = t.up(B_ls, (size_t)B * T * n * m * C, &d_b))) return rc;
+  if (Delta_ls && (rc = t.up(Delta_ls, (size_t)B * T * n * C, &d_d))) return rc;
+  if (u_prev && (rc = t.up(u_prev, (size_t)B * m * 8, &d_up))) return rc;
+  if ((rc = t.up(nullptr, (size_t)B * (T + 1) * n * C, &d_xo))) return rc;
+  if ((rc = t.up(nullptr, (size_t)B * T * m * 8, &d_uo))) return rc;
+  if ((rc = t.up(nullptr, (size_t)B * 8, &d_c))) return rc;
+  if ((rc = t.up(nullptr, (size_t)B * T * (n + 1) * m * C, &d_g))) return rc;
+  a.x_init = (const cplx*)d_x;
+  a.X_bm = (const cplx*)d_xb; a.xbm_stride = bm_per_instance ? (long)((T + 1) * n) : 0;
+  a.U_bm = (const double*)d_ub; a.ubm_stride = bm_per_instance ? (long)(T * m) : 0;
+  a.Q_ls = (const cplx*)d_q; a.R_ls = (const cplx*)d_r;
+  a.A_ls = (const cplx*)d_a; a.B_ls = (const cplx*)d_b; a.D_ls = (const cplx*)d_d; a.u_prev = (const double*)d_up;
+  a.X_opt = (cplx*)d_xo; a.U_opt = (double*)d_uo; a.cost = (double*)d_c; a.gains = (cplx*)d_g;
+  rc = sh->launch_qp(a, nullptr);
+  if (rc) return fail(rc, "qp launch failed");
+  HIP_TRY(hipDeviceSynchronize());
+  if ((rc = down(X_opt, d_xo, (size_t)B * (T + 1) * n * C))) return rc;
+  if ((rc = down(U_opt, d_uo, (size_t)B * T * m * 8))) return rc;
+  if ((rc = down(cost, d_c, (size_t)B * 8))) return rc;
+  return down(gains, d_g, (size_t)B * T * (n + 1) * m * C);
+}
+
+int m4q_plant_step_batch(int32_t B, int32_t dim_x, int32_t dim_u, int32_t plant_kind, double dt, const double* x,
+                         const double* u, const double* op0, const double* ops, int32_t plant_per_instance,
+                         double* x_next) {
+  const m4q::ShapeOps* sh = find_shape_any_order(dim_x, dim_u);
+  if (!sh) return fail(M4Q_E_UNSUPPORTED, "no kernel for dim_x=%d dim_u=%d", dim_x, dim_u);
+  if (B <= 0 || !x || !u || !op0 || !ops || !x_next || (plant_kind != M4Q_PLANT_HAMILTONIAN && plant_kind != M4Q_PLANT_GENERATOR))
+    return fail(M4Q_E_BADARG, "m4q_plant_step_batch: bad argument");
+  int rc = need_device();
+  if (rc) return rc;
+  const size_t n = dim_x, m = dim_u, C = 16;
+  const size_t k = plant_kind == M4Q_PLANT_GENERATOR ? n : (size_t)sh->d;
+  Tmp t;
+  m4q::PlantArgs a{};
+  a.B = B; a.kind = plant_kind; a.dt = dt;
+  void *d_x, *d_u, *d_0, *d_k, *d_o;
+  if ((rc = t.up(x, (size_t)B * n * C, &d_x))) return rc;
+  if ((rc = t.up(u, (size_t)B * m * 8, &d_u))) return rc;
+  if ((rc = t.up(op0, (plant_per_instance ? B : 1) * k * k * C, &d_0))) return rc;
+  if ((rc = t.up(ops, (plant_per_instance ? B : 1) * m * k * k * C, &d_k))) return rc;
+  if ((rc = t.up(nullptr, (size_t)B * n * C, &d_o))) return rc;
+  a.x = (const cplx*)d_x; a.u = (const double*)d_u;
+  a.op0 = (const cplx*)d_0; a.op0_stride = plant_per_instance ? (long)(k * k) : 0;
+  a.ops = (const cplx*)d_k; a.ops_stride = plant_per_instance ? (long)(m * k * k) : 0;
+  a.x_next = (cplx*)d_o;
+  rc = sh->launch_plant(a, nullptr);
+  if (rc) return fail(rc, "plant launch failed");
+  HIP_TRY(hipDeviceSynchronize());
+  return down(x_next, d_o, (size_t)B * n * C);
+}
+
+int m4q_mpc_batch(const m4q_problem* p, int32_t B, const double* models, const double* x0, const double* X_targ,
+                  const double* U_targ, const double* Q, const double* R, const double* Qf, const double* op0,
+                  const double* ops, double* xs, double* us, int32_t* exit_codes, int32_t* steps_done,
+                  int32_t* qp_solves) {
+  if (!p || !models || !x0 || !X_targ || !U_targ || !Q || !R || !Qf || !xs || !us)
+    return fail(M4Q_E_BADARG, "m4q_mpc_batch: bad argument");
+  if (p->plant_kind == M4Q_PLANT_NONE) return fail(M4Q_E_BADARG, "m4q_mpc_batch needs a device plant; use the session API for host plants");
+  if (!op0 || !ops) return fail(M4Q_E_BADARG, "m4q_mpc_batch: plant operators missing");
+  m4q_session* s = nullptr;
+  int rc = m4q_session_create(p, B, -1, &s);
+  if (rc) return rc;
+  struct Guard { m4q_session* s; ~Guard() { m4q_session_destroy(s); } } guard{s};
+  const void* in[9] = {models, x0, X_targ, U_targ, Q, R, Qf, op0, ops};
+  for (int f = M4Q_F_MODELS; f <= M4Q_F_OPS; ++f)
+    if ((rc = m4q_session_upload(s, f, in[f], s->fbytes[f]))) return rc;
+  if ((rc = m4q_session_run(s, 0, p->n_steps))) return rc;
+  if ((rc = m4q_session_sync(s))) return rc;
+  if ((rc = m4q_session_download(s, M4Q_F_XS, xs, s->fbytes[M4Q_F_XS]))) return rc;
+  if ((rc = m4q_session_download(s, M4Q_F_US, us, s->fbytes[M4Q_F_US]))) return rc;
+  if (exit_codes && (rc = m4q_session_download(s, M4Q_F_CODES, exit_codes, s->fbytes[M4Q_F_CODES]))) return rc;
+  if (steps_done && (rc = m4q_session_download(s, M4Q_F_STEPS_DONE, steps_done, s->fbytes[M4Q_F_STEPS_DONE]))) return rc;
+  if (qp_solves && (rc = m4q_session_download(s, M4Q_F_QP_SOLVES, qp_solves, s->fbytes[M4Q_F_QP_SOLVES]))) return rc;
+  return 0;
+}
+
+}  // extern "C"

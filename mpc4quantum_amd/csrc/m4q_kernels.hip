@@ -1,0 +1,437 @@
+// m4q_kernels.hip - kernels for ONE problem shape, selected at compile time:
+//     hipcc --offload-arch=gfx950 -DM4Q_NX=9 -DM4Q_NU=2 -DM4Q_ORDER=1 -c m4q_kernels.hip
+// One wavefront per workgroup; each of its four DPP rows runs one MPC instance (m4q_device.h).
+// The persistent kernel strides over instance quads, so a fixed pool of per-row workspace stays
+// cache resident whatever the ensemble size.
+#include "m4q_args.h"
+#include "m4q_mpc.h"
+
+#ifndef M4Q_NX
+#error "compile with -DM4Q_NX -DM4Q_NU -DM4Q_ORDER"
+#endif
+
+#define M4Q_CAT_(a, b, c, d) a##b##_##c##_##d
+#define M4Q_CAT(a, b, c, d) M4Q_CAT_(a, b, c, d)
+
+namespace m4q {
+// every shape lives in its own namespace: the shapes are linked into one library
+namespace M4Q_CAT(shape_, M4Q_NX, M4Q_NU, M4Q_ORDER) {
+
+constexpr int NX = M4Q_NX;
+constexpr int NU = M4Q_NU;
+constexpr int ORDER = M4Q_ORDER;
+constexpr int DD = (NX == 4) ? 2 : (NX == 9) ? 3 : 4;
+static_assert(DD * DD == NX, "dim_x must be 4, 9 or 16");
+constexpr int NP = PowTab<NU, ORDER>::NP;
+constexpr int PITCH = ModelPitch<NX>::value;
+constexpr int MODEL_ELEMS = (1 + NP) * NX * PITCH;        // per instance, complex elements in LDS
+constexpr int SCRATCH_ELEMS = DD * DD + 2 * NX;           // plant scratch per instance
+constexpr int ROWS = 4;                                    // instances per wavefront
+
+// register budget: waves per SIMD the kernels are compiled for (512 / budget VGPRs per lane)
+#ifndef M4Q_WAVES
+#define M4Q_WAVES ((M4Q_NX <= 4) ? 4 : (M4Q_NX <= 9) ? 2 : 1)
+#endif
+#define M4Q_OCC __attribute__((amdgpu_waves_per_eu(M4Q_WAVES, 8)))
+
+extern __shared__ __align__(16) unsigned char m4q_lds_raw[];
+
+// copy one instance's model (DMDc.A layout, n x n(1+P) row-major) into its LDS block [1+P][n][PITCH]
+__device__ __forceinline__ void stage_model(cplx* dst, const GView& src, int jj) {
+  constexpr int W = NX * (1 + NP);
+  for (int e = jj; e < NX * W; e += 16) {
+    const int i = e / W;
+    const int pk = e - i * W;
+    const int p = pk / NX;
+    const int k = pk - p * NX;
+    dst[(p * NX + i) * PITCH + k] = src.ld<cplx>(e);
+  }
+}
+
+// geometry of one lane inside its quad
+struct LaneGeo {
+  int g, jj, j;
+  bool lane_ok;
+  __device__ __forceinline__ LaneGeo() {
+    const int lane = threadIdx.x;
+    g = lane >> 4;
+    jj = lane & 15;
+    j = jj < NX ? jj : NX - 1;
+    lane_ok = jj < NX;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// The fused closed loop (replaces mpc.py:161-292).
+// ---------------------------------------------------------------------------------------------
+template <int PLANT>
+__global__ __launch_bounds__(64) M4Q_OCC void mpc_kernel(MpcArgs a) {
+  cplx* lds = reinterpret_cast<cplx*>(m4q_lds_raw);
+  const LaneGeo L;
+  const int g = L.g, jj = L.jj, j = L.j;
+  const bool lane_ok = L.lane_ok;
+  const int T = a.T;
+  cplx* mdl = lds + g * MODEL_ELEMS;
+  cplx* scratch = lds + ROWS * MODEL_ELEMS + g * SCRATCH_ELEMS;
+  // workspace of this resident row: uniform base per workgroup, lane part = row within the wave
+  const unsigned sXo = (unsigned)(T + 1) * NX, sUo = (unsigned)T * NU, sG = (unsigned)T * (NX + 1) * NU;
+  const GView Xo = gview(a.ws_Xo, (long)blockIdx.x * ROWS * sXo, g * sXo);
+  const GView Uo = gview(a.ws_Uo, (long)blockIdx.x * ROWS * sUo, g * sUo);
+  const GView gains = gview(a.ws_gains, (long)blockIdx.x * ROWS * sG, g * sG);
+  CostRef cost;
+  cost.Q = a.Q; cost.Qf = a.Qf; cost.q_stride = 0; cost.R = a.R; cost.r_stride = 0;
+  const int nquads = (a.B + ROWS - 1) / ROWS;
+  const unsigned sXs = (unsigned)(a.n_steps + 1) * NX, sUs = (unsigned)a.n_steps * NU;
+
+  for (int quad = blockIdx.x; quad < nquads; quad += gridDim.x) {
+    const long q0 = (long)quad * ROWS;                  // first instance of the quad (uniform)
+    const bool valid = q0 + g < a.B;
+    const unsigned gl = valid ? g : (unsigned)(a.B - 1 - q0);   // row clamped into the ensemble
+    const long b = q0 + gl;
+    __syncthreads();                                   // previous quad is done with the LDS model
+    stage_model(mdl, gview(a.models, q0 * a.model_stride, gl * (unsigned)a.model_stride), jj);
+    __syncthreads();
+
+    const GView Xg = gview(a.Xg, q0 * sXo, gl * sXo);
+    const GView Ug = gview(a.Ug, q0 * sUo, gl * sUo);
+    const GView xs = gview(a.xs, q0 * sXs, gl * sXs);
+    const GView us = gview(a.us, q0 * sUs, gl * sUs);
+    const GView xt = gview(a.x_targ, q0 * a.xt_stride, gl * (unsigned)a.xt_stride);
+    const GView ut = gview(a.u_targ, q0 * a.ut_stride, gl * (unsigned)a.ut_stride);
+    const GView op0 = gview(a.op0, q0 * a.op0_stride, gl * (unsigned)a.op0_stride);
+    const GView ops = gview(a.ops, q0 * a.ops_stride, gl * (unsigned)a.ops_stride);
+    FusedProv<NX, NU, ORDER> prov;
+    prov.mdl = mdl; prov.Xg = Xg; prov.Ug = Ug; prov.j = j;
+
+    int code;
+    int done_steps;
+    if (a.step_begin == 0) {
+      // X_guess = tile(x0), U_guess = 0 (mpc.py:141-142); xs[0] = x0 (:160)
+      const cplx x0 = a.x0[b * NX + j];
+      if (valid && lane_ok) {
+        for (int t = 0; t <= T; ++t) Xg.st<cplx>(t * NX + j, x0);
+        xs.st<cplx>(j, x0);
+      }
+      if (valid) {
+        for (int e = jj; e < T * NU; e += 16) Ug.st<double>(e, 0.0);
+      }
+      code = 0;
+      done_steps = 0;
+    } else {
+      code = a.codes[b];
+      done_steps = a.steps_done[b];
+    }
+    __syncthreads();
+    cplx x_cur = xs.ld<cplx>(a.step_begin * NX + j);
+
+    for (int step = a.step_begin; step < a.step_end; ++step) {
+      const bool alive = valid && code == 0;
+      // target window: X_ref = X_targ[:, :T+1] for steps 0 and 1, then X_targ[:, step-1:...] (mpc.py:145,276)
+      const int w = step <= 1 ? 0 : step - 1;
+      Window win;
+      win.xbm = xt.shifted<cplx>((long)w * NX);
+      win.ubm = ut.shifted<double>((long)w * NU);
+      double lo0[NU], hi0[NU];
+#pragma unroll
+      for (int k = 0; k < NU; ++k) {
+        // u_prev = us[step-1] if step > 1 else U_ref[:, 0] (mpc.py:185)
+        const double up = step > 1 ? us.ld<double>((step - 1) * NU + k) : win.ubm.ld<double>(k);
+        const bool band = (a.flags & QP_DU_BAND) != 0;
+        lo0[k] = band ? up - a.du : -a.sat;
+        hi0[k] = band ? up + a.du : a.sat;
+      }
+      const bool use_ls = !(a.warm_start && step > 1);      // mpc.py:208-213
+      int iter = 0;
+      bool done = !alive;
+      while (__any(!done)) {
+        const bool act = !done;
+        const bool st = act && lane_ok;
+        riccati_backward<NX, NU>(prov, T, win, cost, a.flags, gains, j, st);
+        __syncthreads();
+        const double obj = rollout_forward<NX, NU>(prov, T, x_cur, win, cost, a.flags, gains, a.sat, lo0, hi0, Xo, Uo, j, st);
+        __syncthreads();
+        const bool fail = !finite_d(obj);                    // mpc.py:200-203
+        if (act) ++iter;
+        if (act && fail) { code = 3; done = true; }
+        const bool upd = act && !fail;
+        double alpha = 1.0;
+        bool fin = true;
+        if (use_ls) {
+          ZView<NX, NU> z;
+          z.T = T; z.Xg = Xg; z.Xo = Xo; z.Xt = win.xbm; z.Ug = Ug; z.Uo = Uo; z.Ut = win.ubm;
+          double stepn;
+          line_search<NX, NU>(z, a.Cq, a.Cqf, a.Cr, jj, alpha, stepn);
+          fin = stepn < a.ls_tol;                            // mpc.py:224
+        }
+        __syncthreads();
+        // X_guess += alpha (X_opt - X_guess) (mpc.py:228-229)
+        if (upd && lane_ok) {
+          for (int t = 0; t <= T; ++t) {
+            const cplx xg = Xg.ld<cplx>(t * NX + j), xo = Xo.ld<cplx>(t * NX + j);
+            Xg.st<cplx>(t * NX + j, mk(xg.re + alpha * (xo.re - xg.re), xg.im + alpha * (xo.im - xg.im)));
+          }
+        }
+        if (upd) {
+          for (int e = jj; e < T * NU; e += 16) {
+            const double ug = Ug.ld<double>(e);
+            Ug.st<double>(e, ug + alpha * (Uo.ld<double>(e) - ug));
+          }
+        }
+        if (upd && (fin || iter >= a.max_iter)) done = true;
+        __syncthreads();
+      }
+      if (alive && jj == 0) a.qp_solves[b * a.n_steps + step] = iter;
+      const bool ok = alive && code == 0;
+      // apply U_opt[:, 0] (mpc.py:250), propagate the plant (mpc.py:256-260)
+      double uapp[NU];
+#pragma unroll
+      for (int k = 0; k < NU; ++k) uapp[k] = Uo.ld<double>(k);
+      if (ok && jj == 0) {
+#pragma unroll
+        for (int k = 0; k < NU; ++k) us.st<double>(step * NU + k, uapp[k]);
+      }
+      if constexpr (PLANT == PLANT_HAMILTONIAN) {
+        const cplx xn = plant_hamiltonian<NX, NU, DD>(x_cur, uapp, op0, ops, a.dt, scratch, j, jj);
+        if (ok) x_cur = xn;
+        if (ok && lane_ok) xs.st<cplx>((step + 1) * NX + j, xn);
+      } else if constexpr (PLANT == PLANT_GENERATOR) {
+        const cplx xn = plant_generator<NX, NU>(x_cur, uapp, op0, ops, a.dt, j);
+        if (ok) x_cur = xn;
+        if (ok && lane_ok) xs.st<cplx>((step + 1) * NX + j, xn);
+      }
+      // shift_guess (mpc.py:71-73,271-272): drop column 0, repeat the last
+      if (ok && lane_ok) {
+        cplx nxt = Xg.ld<cplx>(1 * NX + j);
+        for (int t = 0; t < T; ++t) {
+          const cplx cur = nxt;
+          if (t + 2 <= T) nxt = Xg.ld<cplx>((t + 2) * NX + j);
+          Xg.st<cplx>(t * NX + j, cur);
+        }
+      }
+      if (ok && jj < NU) {
+        for (int t = 0; t + 1 < T; ++t) Ug.st<double>(t * NU + jj, Ug.ld<double>((t + 1) * NU + jj));
+      }
+      if (ok) done_steps = step + 1;
+      __syncthreads();
+      if constexpr (PLANT == PLANT_NONE) {
+        // the caller writes xs[step+1] before the next launch; nothing to carry inside this one
+        if (step + 1 < a.step_end) x_cur = xs.ld<cplx>((step + 1) * NX + j);
+      }
+    }
+    if (valid && jj == 0) {
+      a.codes[b] = code;
+      a.steps_done[b] = done_steps;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// WrapModel.get_model_along_traj for B trajectories (linearize.py:61-70)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) M4Q_OCC void linearize_kernel(LinArgs a) {
+  cplx* lds = reinterpret_cast<cplx*>(m4q_lds_raw);
+  const LaneGeo L;
+  const int g = L.g, jj = L.jj, j = L.j;
+  cplx* mdl = lds + g * MODEL_ELEMS;
+  const int nquads = (a.B + ROWS - 1) / ROWS;
+  const unsigned sX = (unsigned)a.T * NX, sU = (unsigned)a.T * NU;
+  for (int quad = blockIdx.x; quad < nquads; quad += gridDim.x) {
+    const long q0 = (long)quad * ROWS;
+    const bool valid = q0 + g < a.B;
+    const unsigned gl = valid ? g : (unsigned)(a.B - 1 - q0);
+    __syncthreads();
+    stage_model(mdl, gview(a.models, q0 * a.model_stride, gl * (unsigned)a.model_stride), jj);
+    __syncthreads();
+    FusedProv<NX, NU, ORDER> prov;
+    prov.mdl = mdl;
+    prov.Xg = gview(a.X, q0 * sX, gl * sX);
+    prov.Ug = gview(a.U, q0 * sU, gl * sU);
+    prov.j = j;
+    const GView Ao = gview(a.A_ls, q0 * sX * NX, gl * sX * NX);
+    const GView Bo = gview(a.B_ls, q0 * sX * NU, gl * sX * NU);
+    const GView Do = gview(a.D_ls, q0 * sX, gl * sX);
+    for (int t = 0; t < a.T; ++t) {
+      cplx Ac[NX];
+      prov.col(t, Ac);
+      cplx av, Brow[NU], dlt;
+      prov.rows(t, czero(), av, Brow, dlt);
+      if (valid && L.lane_ok) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) Ao.st<cplx>((t * NX + i) * NX + j, Ac[i]);
+#pragma unroll
+        for (int k = 0; k < NU; ++k) Bo.st<cplx>((t * NX + j) * NU + k, Brow[k]);
+        Do.st<cplx>(t * NX + j, dlt);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// quad_program for B explicit linear time-varying problems (optimize.py:12-60 / lqr.py:14-79)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) M4Q_OCC void qp_kernel(QpArgs a) {
+  const LaneGeo L;
+  const int g = L.g, jj = L.jj, j = L.j;
+  const int T = a.T;
+  const int nquads = (a.B + ROWS - 1) / ROWS;
+  CostRef cost;
+  cost.Q = a.Q_ls; cost.Qf = a.Q_ls + (long)T * NX * NX; cost.q_stride = (long)NX * NX;
+  cost.R = a.R_ls; cost.r_stride = (long)NU * NU;
+  const unsigned sX = (unsigned)(T + 1) * NX, sU = (unsigned)T * NU, sG = (unsigned)T * (NX + 1) * NU;
+  const unsigned sA = (unsigned)T * NX * NX, sB = (unsigned)T * NX * NU, sD = (unsigned)T * NX;
+  for (int quad = blockIdx.x; quad < nquads; quad += gridDim.x) {
+    const long q0 = (long)quad * ROWS;
+    const bool valid = q0 + g < a.B;
+    const unsigned gl = valid ? g : (unsigned)(a.B - 1 - q0);
+    const long b = q0 + gl;
+    ExplicitProv<NX, NU> prov;
+    prov.A_ls = gview(a.A_ls, q0 * sA, gl * sA);
+    prov.B_ls = gview(a.B_ls, q0 * sB, gl * sB);
+    prov.has_delta = a.D_ls != nullptr;
+    prov.D_ls = gview(a.D_ls ? a.D_ls : a.A_ls, q0 * sD, gl * sD);
+    prov.j = j;
+    Window win;
+    win.xbm = gview(a.X_bm, q0 * a.xbm_stride, gl * (unsigned)a.xbm_stride);
+    win.ubm = gview(a.U_bm, q0 * a.ubm_stride, gl * (unsigned)a.ubm_stride);
+    const GView gains = gview(a.gains, q0 * sG, gl * sG);
+    const GView Xo = gview(a.X_opt, q0 * sX, gl * sX);
+    const GView Uo = gview(a.U_opt, q0 * sU, gl * sU);
+    const bool st = valid && L.lane_ok;
+    riccati_backward<NX, NU>(prov, T, win, cost, a.flags, gains, j, st);
+    __syncthreads();
+    double lo0[NU], hi0[NU];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+      const bool band = (a.flags & QP_DU_BAND) != 0 && a.u_prev != nullptr;
+      const double up = band ? a.u_prev[b * NU + k] : 0.0;
+      lo0[k] = band ? up - a.du : -a.sat;
+      hi0[k] = band ? up + a.du : a.sat;
+    }
+    const cplx x0 = a.x_init[b * NX + j];
+    const double obj = rollout_forward<NX, NU>(prov, T, x0, win, cost, a.flags, gains, a.sat, lo0, hi0, Xo, Uo, j, st);
+    if (valid && jj == 0) a.cost[b] = obj;
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One held-control plant step for B states (experiment.py:202-212)
+// ---------------------------------------------------------------------------------------------
+template <int PLANT>
+__global__ __launch_bounds__(64) M4Q_OCC void plant_kernel(PlantArgs a) {
+  cplx* lds = reinterpret_cast<cplx*>(m4q_lds_raw);
+  const LaneGeo L;
+  const int g = L.g, jj = L.jj, j = L.j;
+  cplx* scratch = lds + g * SCRATCH_ELEMS;
+  const int nquads = (a.B + ROWS - 1) / ROWS;
+  for (int quad = blockIdx.x; quad < nquads; quad += gridDim.x) {
+    const long q0 = (long)quad * ROWS;
+    const bool valid = q0 + g < a.B;
+    const unsigned gl = valid ? g : (unsigned)(a.B - 1 - q0);
+    const long b = q0 + gl;
+    const cplx x = a.x[b * NX + j];
+    double u[NU];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) u[k] = a.u[b * NU + k];
+    const GView op0 = gview(a.op0, q0 * a.op0_stride, gl * (unsigned)a.op0_stride);
+    const GView ops = gview(a.ops, q0 * a.ops_stride, gl * (unsigned)a.ops_stride);
+    cplx xn;
+    if constexpr (PLANT == PLANT_HAMILTONIAN)
+      xn = plant_hamiltonian<NX, NU, DD>(x, u, op0, ops, a.dt, scratch, j, jj);
+    else
+      xn = plant_generator<NX, NU>(x, u, op0, ops, a.dt, j);
+    if (valid && jj < NX) a.x_next[b * NX + j] = xn;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launchers for this shape
+// ---------------------------------------------------------------------------------------------
+static size_t mpc_lds_bytes() { return sizeof(double) * 2 * (size_t)(ROWS * MODEL_ELEMS + ROWS * SCRATCH_ELEMS); }
+
+template <class K>
+static int prep_lds(K kern, size_t bytes) {
+  if (bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return -(int)e;
+  }
+  return 0;
+}
+
+static int launch_mpc(const MpcArgs& a, int plant_kind, int grid, hipStream_t s) {
+  const size_t lds = mpc_lds_bytes();
+  int rc = 0;
+  if (plant_kind == PLANT_HAMILTONIAN) {
+    if ((rc = prep_lds(mpc_kernel<PLANT_HAMILTONIAN>, lds))) return rc;
+    hipLaunchKernelGGL(mpc_kernel<PLANT_HAMILTONIAN>, dim3(grid), dim3(64), lds, s, a);
+  } else if (plant_kind == PLANT_GENERATOR) {
+    if ((rc = prep_lds(mpc_kernel<PLANT_GENERATOR>, lds))) return rc;
+    hipLaunchKernelGGL(mpc_kernel<PLANT_GENERATOR>, dim3(grid), dim3(64), lds, s, a);
+  } else {
+    if ((rc = prep_lds(mpc_kernel<PLANT_NONE>, lds))) return rc;
+    hipLaunchKernelGGL(mpc_kernel<PLANT_NONE>, dim3(grid), dim3(64), lds, s, a);
+  }
+  return -(int)hipGetLastError();
+}
+
+static int occupancy(int plant_kind) {
+  int nb = 0;
+  const size_t lds = mpc_lds_bytes();
+  hipError_t e;
+  if (plant_kind == PLANT_HAMILTONIAN)
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mpc_kernel<PLANT_HAMILTONIAN>, 64, lds);
+  else if (plant_kind == PLANT_GENERATOR)
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mpc_kernel<PLANT_GENERATOR>, 64, lds);
+  else
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mpc_kernel<PLANT_NONE>, 64, lds);
+  if (e != hipSuccess) return -(int)e;
+  return nb;
+}
+
+static int grid_for(int B) {
+  const int nquads = (B + ROWS - 1) / ROWS;
+  return nquads < 4096 ? (nquads > 0 ? nquads : 1) : 4096;
+}
+
+static int launch_linearize(const LinArgs& a, hipStream_t s) {
+  const size_t lds = sizeof(double) * 2 * (size_t)(ROWS * MODEL_ELEMS);
+  int rc = prep_lds(linearize_kernel, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(linearize_kernel, dim3(grid_for(a.B)), dim3(64), lds, s, a);
+  return -(int)hipGetLastError();
+}
+
+static int launch_qp(const QpArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(qp_kernel, dim3(grid_for(a.B)), dim3(64), 0, s, a);
+  return -(int)hipGetLastError();
+}
+
+static int launch_plant(const PlantArgs& a, hipStream_t s) {
+  const size_t lds = sizeof(double) * 2 * (size_t)(ROWS * SCRATCH_ELEMS);
+  if (a.kind == PLANT_HAMILTONIAN)
+    hipLaunchKernelGGL(plant_kernel<PLANT_HAMILTONIAN>, dim3(grid_for(a.B)), dim3(64), lds, s, a);
+  else
+    hipLaunchKernelGGL(plant_kernel<PLANT_GENERATOR>, dim3(grid_for(a.B)), dim3(64), lds, s, a);
+  return -(int)hipGetLastError();
+}
+
+static int power_list(int32_t* out) {
+  constexpr PowTab<NU, ORDER> tab{};
+  for (int p = 0; p < PowTab<NU, ORDER>::COUNT; ++p)
+    for (int k = 0; k < NU; ++k) out[p * NU + k] = tab.e[p][k];
+  return PowTab<NU, ORDER>::COUNT;
+}
+
+static const ShapeOps* shape_ops() {
+  static const ShapeOps ops = {NX, NU, ORDER, NP, DD, mpc_lds_bytes, launch_mpc, launch_linearize, launch_qp, launch_plant,
+                               power_list, occupancy};
+  return &ops;
+}
+
+}  // namespace shape_<nx>_<nu>_<order>
+}  // namespace m4q
+
+// registration symbol of this shape: m4q_shape_<nx>_<nu>_<order>
+extern "C" __attribute__((visibility("hidden"))) const m4q::ShapeOps* M4Q_CAT(m4q_shape_, M4Q_NX, M4Q_NU, M4Q_ORDER)() {
+  return m4q::M4Q_CAT(shape_, M4Q_NX, M4Q_NU, M4Q_ORDER)::shape_ops();
+}

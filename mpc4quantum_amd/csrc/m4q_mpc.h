@@ -1,0 +1,727 @@
+// m4q_mpc.h - per-instance MPC numerics on one 16-lane DPP row (see m4q_device.h for the layout).
+//
+// Reference arithmetic being replaced (citations into /root/reference/):
+//   bilinear linearisation      mpc4quantum/linearize.py:34-70   (WrapModel.df_dx / df_du / Delta)
+//   finite-horizon Riccati      mpc4quantum/lqr.py:28-79         (+ Delta and xbar_{t+1}: optimize.py:27-41,54)
+//   line search                 mpc4quantum/mpc.py:101-125
+//   plant step                  mpc4quantum/experiment.py:190-212 (ODE solved exactly: Pade-13 expm)
+#pragma once
+#include "m4q_device.h"
+
+namespace m4q {
+
+// QP semantics flags (mirrored in include/m4q.h)
+enum : int {
+  QP_REF_LQR = 1,   // reproduce lqr.py as written (no Delta, xbar_{t+1}==xbar_t, cost built on xbar, absolute cost)
+  QP_DU_BAND = 2,   // clip the first control to u_prev +- du as well (optimize.py:29-30)
+};
+
+// ---------------------------------------------------------------------------------------------
+// Control-monomial table, in the order of linearize.create_power_list (linearize.py:92-116):
+// the exponent of the LAST control is the outermost loop, total degree <= ORDER.
+// ---------------------------------------------------------------------------------------------
+constexpr int binom(int n, int k) {
+  int r = 1;
+  for (int i = 1; i <= k; ++i) r = r * (n - k + i) / i;
+  return r;
+}
+
+template <int NU, int ORDER>
+struct PowTab {
+  static constexpr int COUNT = binom(ORDER + NU, NU);   // including the constant
+  static constexpr int NP = COUNT - 1;
+  int e[COUNT][NU > 0 ? NU : 1];
+  constexpr PowTab() : e{} {
+    // enumerate [0..ORDER]^NU with the first control as the fastest digit, keep total degree <= ORDER
+    int total = 1;
+    for (int k = 0; k < NU; ++k) total *= (ORDER + 1);
+    int idx = 0;
+    for (int code = 0; code < total; ++code) {
+      int c = code, sum = 0;
+      int cur[3] = {0, 0, 0};
+      for (int k = 0; k < NU; ++k) {
+        cur[k] = c % (ORDER + 1);
+        c /= (ORDER + 1);
+        sum += cur[k];
+      }
+      if (sum <= ORDER) {
+        for (int k = 0; k < NU; ++k) e[idx][k] = cur[k];
+        ++idx;
+      }
+    }
+  }
+};
+
+template <int E>
+__device__ __forceinline__ double ipow(double u) {
+  if constexpr (E <= 0) return 1.0;
+  else if constexpr (E == 1) return u;
+  else return u * ipow<E - 1>(u);
+}
+
+// polyu_p(u) and d polyu_p / d u_k for the NP non-constant monomials
+template <int NU, int ORDER>
+struct Poly {
+  static constexpr PowTab<NU, ORDER> tab{};
+  static constexpr int NP = PowTab<NU, ORDER>::NP;
+  double pu[NP];
+  double dpu[NU][NP];
+  __device__ __forceinline__ void eval(const double (&u)[NU]) {
+    static_for<0, NP>([&](auto pp) {
+      constexpr int p = decltype(pp)::value;
+      double v = 1.0;
+      static_for<0, NU>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        v *= ipow<tab.e[p + 1][k]>(u[k]);
+      });
+      pu[p] = v;
+      static_for<0, NU>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        constexpr int ek = tab.e[p + 1][k];
+        if constexpr (ek == 0) {
+          dpu[k][p] = 0.0;
+        } else {
+          double d = (double)ek * ipow<ek - 1>(u[k]);
+          static_for<0, NU>([&](auto ll) {
+            constexpr int l = decltype(ll)::value;
+            if constexpr (l != k) d *= ipow<tab.e[p + 1][l]>(u[l]);
+          });
+          dpu[k][p] = d;
+        }
+      });
+    });
+  }
+};
+
+template <int NX>
+struct ModelPitch {
+  // row pitch (in complex elements) of a model block in LDS: 16 -> 17 keeps the row-owner
+  // reads (lane stride = pitch * 16 B) off a single bank
+  static constexpr int value = (NX % 16 == 0) ? NX + 1 : NX;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Linearisation providers.  col(): column j of A_t.  rows(): for the row this lane owns,
+// (A_t v)_j for a distributed vector v, row j of B_t and Delta_t[j].
+// All views are positioned on this lane's instance; lane-dependent parts are 32-bit offsets.
+// ---------------------------------------------------------------------------------------------
+template <int NX, int NU, int ORDER>
+struct FusedProv {
+  static constexpr int NP = PowTab<NU, ORDER>::NP;
+  static constexpr int PITCH = ModelPitch<NX>::value;
+  const cplx* mdl;    // LDS, [1+NP][NX][PITCH]: block 0 = A, block 1+p = N_p   (model.py:95-103)
+  GView Xg;           // guess trajectory [T+1][NX], positioned at element 0 of this instance
+  GView Ug;           // [T][NU]
+  int j;              // lane in row, clamped to NX-1
+
+  __device__ __forceinline__ void load_u(int t, double (&u)[NU]) const {
+#pragma unroll
+    for (int k = 0; k < NU; ++k) u[k] = Ug.ld<double>(t * NU + k);
+  }
+  // A_t = A + sum_p polyu_p N_p   (linearize.py:43-48)
+  __device__ __forceinline__ void col(int t, cplx (&Ac)[NX]) const {
+    double u[NU];
+    load_u(t, u);
+    Poly<NU, ORDER> po;
+    po.eval(u);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      cplx a = mdl[i * PITCH + j];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) cmac_r(a, mdl[((1 + p) * NX + i) * PITCH + j], po.pu[p]);
+      Ac[i] = a;
+    }
+  }
+  // B_t[:,k] = sum_p (N_p x) c_kp dmono_kp(u)  (linearize.py:50-59);  Delta_t = f - A_t x - B_t u = -B_t u (:68-69)
+  __device__ __forceinline__ void rows(int t, cplx v, cplx& av, cplx (&Brow)[NU], cplx& dlt) const {
+    double u[NU];
+    load_u(t, u);
+    Poly<NU, ORDER> po;
+    po.eval(u);
+    const cplx xg = Xg.ld<cplx>(t * NX + j);
+    cplx nx[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) nx[p] = czero();
+    av = czero();
+    static_for<0, NX>([&](auto kk) {
+      constexpr int k = decltype(kk)::value;
+      cplx a = mdl[j * PITCH + k];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const cplx np = mdl[((1 + p) * NX + j) * PITCH + k];
+        cmac_r(a, np, po.pu[p]);
+        cmac_bc<k>(nx[p], xg, np);
+      }
+      cmac_bc<k>(av, v, a);
+    });
+    dlt = czero();
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+      cplx b = czero();
+#pragma unroll
+      for (int p = 0; p < NP; ++p) cmac_r(b, nx[p], po.dpu[k][p]);
+      Brow[k] = b;
+      cmac_r(dlt, b, -u[k]);
+    }
+  }
+};
+
+template <int NX, int NU>
+struct ExplicitProv {
+  GView A_ls;   // [T][NX][NX]   positioned at this instance
+  GView B_ls;   // [T][NX][NU]
+  GView D_ls;   // [T][NX]
+  bool has_delta;
+  int j;
+  __device__ __forceinline__ void col(int t, cplx (&Ac)[NX]) const {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) Ac[i] = A_ls.ld<cplx>((t * NX + i) * NX + j);
+  }
+  __device__ __forceinline__ void rows(int t, cplx v, cplx& av, cplx (&Brow)[NU], cplx& dlt) const {
+    av = czero();
+    static_for<0, NX>([&](auto kk) {
+      constexpr int k = decltype(kk)::value;
+      cmac_bc<k>(av, v, A_ls.ld<cplx>((t * NX + j) * NX + k));
+    });
+#pragma unroll
+    for (int k = 0; k < NU; ++k) Brow[k] = B_ls.ld<cplx>((t * NX + j) * NU + k);
+    dlt = has_delta ? D_ls.ld<cplx>(t * NX + j) : czero();
+  }
+};
+
+// Stage costs (shared by the ensemble, wave-uniform pointers).  Q(t) for t < T, Qf at t == T; R(t).
+struct CostRef {
+  const cplx* Q;
+  const cplx* Qf;
+  long q_stride;   // elements between Q(t) and Q(t+1); 0 = constant
+  const cplx* R;
+  long r_stride;
+  __device__ __forceinline__ const cplx* q(int t, int T) const { return t == T ? Qf : Q + (long)t * q_stride; }
+  __device__ __forceinline__ const cplx* r(int t) const { return R + (long)t * r_stride; }
+};
+
+// The horizon window of one instance: targets (views at window column 0, element 0).
+struct Window {
+  GView xbm;   // [T+1][NX]
+  GView ubm;   // [T][NU]
+};
+
+// ---------------------------------------------------------------------------------------------
+// Backward Riccati sweep on z = [x - xbar; 1], V = [[P, p], [p^H, pi]]  (lqr.py:28-65).
+// pi never enters a gain and is not carried.  Lane j owns column j of P and element j of p.
+//   K_t = -(R + B^H P B)^-1 [B^H P A_t , B^H (P c_t + p)]           lqr.py:61-62
+//   S   = [A_t + B Kx , c_t + B k]
+//   P  <- Q + Kx^H R Kx + Sx^H P Sx ;  p <- -Q r + Kx^H R k + Sx^H (P s + p)   lqr.py:64-65
+// gains layout: [t][col 0..NX][NU]  (col NX holds k); the view is positioned at the instance.
+// ---------------------------------------------------------------------------------------------
+#define M4Q_PHASE() __builtin_amdgcn_sched_barrier(0)
+// the LDS model and the shared cost matrices are loop invariant; without this the compiler hoists
+// their loads out of the horizon loops and keeps (then spills) hundreds of VGPRs of them
+#define M4Q_NO_HOIST() asm volatile("" ::: "memory")
+
+template <int NX, int NU, class Prov>
+__device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const Window& win, const CostRef& cost, int flags,
+                                                  const GView& gains, int j, bool store_ok) {
+  const bool ref = (flags & QP_REF_LQR) != 0;
+  cplx Pc[NX];
+  cplx pv = czero();
+  {
+    const cplx* Qt = cost.q(T, T);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) Pc[i] = Qt[i * NX + j];
+    if (ref) {
+      const cplx r = win.xbm.ld<cplx>(T * NX + j);
+      static_for<0, NX>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        cmac_bc<i>(pv, r, cneg(Qt[j * NX + i]));
+      });
+    }
+  }
+  for (int t = T - 1; t >= 0; --t) {
+    M4Q_NO_HOIST();
+    cplx Ac[NX];
+    prov.col(t, Ac);
+    M4Q_PHASE();
+    const cplx xb = win.xbm.ld<cplx>(t * NX + j);
+    const cplx xb1 = win.xbm.ld<cplx>((t + 1) * NX + j);
+    double ub[NU];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) ub[k] = win.ubm.ld<double>(t * NU + k);
+    cplx ax, Brow[NU], dlt;
+    prov.rows(t, xb, ax, Brow, dlt);
+    M4Q_PHASE();
+
+    // affine column of the augmented dynamics
+    cplx c = ax;
+#pragma unroll
+    for (int k = 0; k < NU; ++k) cmac_r(c, Brow[k], ub[k]);
+    c = ref ? csub(c, xb) : cadd(c, csub(dlt, xb1));          // lqr.py:45  |  optimize.py:41
+
+    // BhP[k] = (B^H P)[k][j]
+    cplx BhP[NU];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) BhP[k] = czero();
+    static_for<0, NX>([&](auto ii) {
+      constexpr int i = decltype(ii)::value;
+#pragma unroll
+      for (int k = 0; k < NU; ++k) cmac_cjbc<i>(BhP[k], Brow[k], Pc[i]);
+    });
+    const cplx w = cadd(matvec_h<NX>(Pc, c), pv);             // (P c + p)_j
+
+    // G = R + B^H P B (replicated), h = B^H (P c + p)
+    const cplx* Rt = cost.r(t);
+    cplx g[NU][NU], ginv[NU][NU], h[NU];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+#pragma unroll
+      for (int l = k; l < NU; ++l) {
+        const cplx prod = cmul(BhP[k], Brow[l]);
+        const cplx rkl = Rt[k * NU + l];
+        if (l == k) g[k][l] = mk(rkl.re + rowsum<NX>(prod.re), 0.0);
+        else g[k][l] = cadd(rkl, rowsum<NX>(prod));
+      }
+      h[k] = rowsum<NX>(cmul(cconj(Brow[k]), w));
+    }
+    herm_inverse<NU>(g, ginv);
+    M4Q_PHASE();
+
+    // Hh[l] = (B^H P A_t)[l][j]
+    cplx Hh[NU];
+#pragma unroll
+    for (int l = 0; l < NU; ++l) Hh[l] = czero();
+    static_for<0, NX>([&](auto ii) {
+      constexpr int i = decltype(ii)::value;
+#pragma unroll
+      for (int l = 0; l < NU; ++l) cmac_bc<i>(Hh[l], BhP[l], Ac[i]);
+    });
+    cplx Kx[NU], kk[NU];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+      cplx a = czero(), b = czero();
+#pragma unroll
+      for (int l = 0; l < NU; ++l) {
+        cmac(a, ginv[k][l], Hh[l]);
+        cmac(b, ginv[k][l], h[l]);
+      }
+      Kx[k] = cneg(a);
+      kk[k] = cneg(b);
+    }
+    if (store_ok) {
+      const unsigned gt = (unsigned)t * (NX + 1) * NU;
+#pragma unroll
+      for (int k = 0; k < NU; ++k) gains.st<cplx>(gt + j * NU + k, Kx[k]);
+      if (j == 0) {
+#pragma unroll
+        for (int k = 0; k < NU; ++k) gains.st<cplx>(gt + NX * NU + k, kk[k]);
+      }
+    }
+
+    // closed loop: Sx = A_t + B Kx (column j, in place), s = c + B k
+    static_for<0, NX>([&](auto ii) {
+      constexpr int i = decltype(ii)::value;
+#pragma unroll
+      for (int k = 0; k < NU; ++k) cmac_bc<i>(Ac[i], Brow[k], Kx[k]);
+    });
+    cplx s = c;
+#pragma unroll
+    for (int k = 0; k < NU; ++k) cmac(s, Brow[k], kk[k]);
+    M4Q_PHASE();
+
+    cplx PSc[NX];
+    matmul_cols<NX>(PSc, Pc, Ac);                              // P Sx
+    const cplx ws = cadd(matvec_h<NX>(Pc, s), pv);            // (P s + p)_j
+    M4Q_PHASE();
+
+    cplx RK[NU], Rk[NU];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+      RK[k] = czero();
+      Rk[k] = czero();
+#pragma unroll
+      for (int l = 0; l < NU; ++l) {
+        const cplx rkl = Rt[k * NU + l];
+        cmac(RK[k], rkl, Kx[l]);
+        cmac(Rk[k], rkl, kk[l]);
+      }
+    }
+    const cplx* Qt = cost.q(t, T);
+    cplx Pn[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) Pn[i] = Qt[i * NX + j];
+    matmul_cols_hn_acc<NX>(Pn, Ac, PSc);                       // + Sx^H P Sx
+    static_for<0, NX>([&](auto ii) {
+      constexpr int i = decltype(ii)::value;
+#pragma unroll
+      for (int k = 0; k < NU; ++k) cmac_cjbc<i>(Pn[i], Kx[k], RK[k]);   // + Kx^H R Kx
+    });
+    cplx pn = matvec_h<NX>(Ac, ws);                            // Sx^H (P s + p)
+#pragma unroll
+    for (int k = 0; k < NU; ++k) cmac_cj(pn, Kx[k], Rk[k]);
+    if (ref) {
+      static_for<0, NX>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        cmac_bc<i>(pn, xb, cneg(Qt[j * NX + i]));              // - Q xbar_t   (lqr.py:54-58)
+      });
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) Pc[i] = Pn[i];
+    pv = pn;
+    M4Q_PHASE();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Forward rollout with clipping (lqr.py:67-79; dynamics with Delta: optimize.py:41).
+// x distributed (lane j holds x_t[j]).  Returns the objective, replicated over the row.
+// ---------------------------------------------------------------------------------------------
+template <int NX, int NU, class Prov>
+__device__ __forceinline__ double rollout_forward(const Prov& prov, int T, cplx x0, const Window& win, const CostRef& cost,
+                                                   int flags, const GView& gains, double sat, const double (&lo0)[NU],
+                                                   const double (&hi0)[NU], const GView& Xo, const GView& Uo, int j,
+                                                   bool store_ok) {
+  const bool ref = (flags & QP_REF_LQR) != 0;
+  cplx x = x0;
+  if (store_ok) Xo.st<cplx>(j, x);
+  double cx = 0.0;     // per-lane share of the state cost
+  double cu = 0.0;     // control cost (replicated)
+  for (int t = 0; t < T; ++t) {
+    M4Q_NO_HOIST();
+    const cplx xb = win.xbm.ld<cplx>(t * NX + j);
+    double ub[NU];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) ub[k] = win.ubm.ld<double>(t * NU + k);
+    const unsigned gt = (unsigned)t * (NX + 1) * NU;
+    cplx Kx[NU];
+    double kre[NU];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+      Kx[k] = gains.ld<cplx>(gt + j * NU + k);
+      kre[k] = gains.ld<cplx>(gt + NX * NU + k).re;
+    }
+    cplx ax, Brow[NU], dlt;
+    prov.rows(t, x, ax, Brow, dlt);
+    M4Q_PHASE();
+    const cplx dx = csub(x, xb);
+    double u[NU];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+      const double part = Kx[k].re * dx.re - Kx[k].im * dx.im;
+      double uk = rowsum<NX>(part) + kre[k] + ub[k];                   // lqr.py:75
+      double lo = -sat, hi = sat;
+      if (t == 0) {
+        lo = fmax(lo, lo0[k]);
+        hi = fmin(hi, hi0[k]);
+      }
+      uk = fmin(fmax(uk, lo), hi);                                     // lqr.py:76
+      u[k] = uk;
+    }
+    cplx xn = ref ? ax : cadd(ax, dlt);
+#pragma unroll
+    for (int k = 0; k < NU; ++k) cmac_r(xn, Brow[k], u[k]);
+    // objective
+    const cplx* Rt = cost.r(t);
+    {
+      const cplx e = ref ? xn : dx;
+      const cplx* Qt = cost.q(ref ? t + 1 : t, T);
+      cplx qe = czero();
+      static_for<0, NX>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        cmac_bc<i>(qe, e, Qt[j * NX + i]);
+      });
+      cx += e.re * qe.re + e.im * qe.im;
+#pragma unroll
+      for (int k = 0; k < NU; ++k) {
+#pragma unroll
+        for (int l = 0; l < NU; ++l) {
+          const double ek = ref ? u[k] : u[k] - ub[k];
+          const double el = ref ? u[l] : u[l] - ub[l];
+          cu += ek * Rt[k * NU + l].re * el;
+        }
+      }
+    }
+    x = xn;
+    if (store_ok) {
+      Xo.st<cplx>((t + 1) * NX + j, x);
+      if (j == 0) {
+#pragma unroll
+        for (int k = 0; k < NU; ++k) Uo.st<double>(t * NU + k, u[k]);
+      }
+    }
+    M4Q_PHASE();
+  }
+  if (!ref) {
+    const cplx e = csub(x, win.xbm.ld<cplx>(T * NX + j));
+    const cplx* Qt = cost.q(T, T);
+    cplx qe = czero();
+    static_for<0, NX>([&](auto ii) {
+      constexpr int i = decltype(ii)::value;
+      cmac_bc<i>(qe, e, Qt[j * NX + i]);
+    });
+    cx += e.re * qe.re + e.im * qe.im;
+  }
+  return rowsum<NX>(cx) + cu;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Line search of mpc.iqp_line_search (mpc.py:101-125), as written: Z stacks
+// [Re X.flatten(), Im X.flatten(), Re U.flatten(), Im U.flatten()] with X flattened row-major
+// over (n, T+1), while the cost is block-diagonal with one 2n x 2n block per horizon node and one
+// 2m x 2m block per control.  Cq/Cqf/Cr are the symmetrised real blocks (host-built).
+// jj is the UNCLAMPED lane in the row: all 16 lanes take part.  Views are positioned at element 0
+// of the instance (no lane term).
+// ---------------------------------------------------------------------------------------------
+template <int NX, int NU>
+struct ZView {
+  int T;
+  GView Xg, Xo, Xt;   // [T+1][NX]
+  GView Ug, Uo, Ut;   // [T][NU]
+  // returns (guess - target, opt - guess) at flat index q of Z
+  __device__ __forceinline__ void at(int q, double& e, double& d) const {
+    const int nxt = NX * (T + 1);
+    double g = 0.0, o = 0.0, tg = 0.0;
+    if (q < 2 * nxt) {
+      const bool im = q >= nxt;
+      const int f = im ? q - nxt : q;
+      const int i = f / (T + 1);
+      const int t = f - i * (T + 1);
+      const unsigned idx = 2 * (t * NX + i) + (im ? 1 : 0);
+      g = Xg.ld<double>(idx);
+      o = Xo.ld<double>(idx);
+      tg = Xt.ld<double>(idx);
+    } else {
+      const int f = q - 2 * nxt;
+      if (f < NU * T) {
+        const int k = f / T;
+        const int t = f - k * T;
+        g = Ug.ld<double>(t * NU + k);
+        o = Uo.ld<double>(t * NU + k);
+        tg = Ut.ld<double>(t * NU + k);
+      }
+    }
+    e = g - tg;
+    d = o - g;
+  }
+};
+
+template <int S, class ZV>
+__device__ __forceinline__ void ls_block(const ZV& z, int base, const double* C, int jj, double& num, double& den,
+                                         double& nrm) {
+  // rows jj and jj+16 of an S x S block (S <= 32)
+  constexpr int NR = (S + 15) / 16;
+  double e[NR], d[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int row = jj + 16 * r;
+    e[r] = 0.0;
+    d[r] = 0.0;
+    if (row < S) z.at(base + row, e[r], d[r]);
+  }
+  double ye[NR], yd[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) { ye[r] = 0.0; yd[r] = 0.0; }
+  static_for<0, S>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int row = jj + 16 * r;
+      const double w = (row < S) ? C[row * S + c] : 0.0;
+      fmac_bc<c % 16>(ye[r], e[c / 16], w);
+      fmac_bc<c % 16>(yd[r], d[c / 16], w);
+    }
+  });
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    num = fma(ye[r], d[r], num);
+    den = fma(yd[r], d[r], den);
+    nrm = fma(d[r], d[r], nrm);
+  }
+}
+
+template <int NX, int NU>
+__device__ __forceinline__ void line_search(const ZView<NX, NU>& z, const double* Cq, const double* Cqf,
+                                            const double* Cr, int jj, double& alpha, double& step_norm) {
+  const int T = z.T;
+  double num = 0.0, den = 0.0, nrm = 0.0;
+  for (int b = 0; b <= T; ++b) ls_block<2 * NX>(z, 2 * NX * b, b == T ? Cqf : Cq, jj, num, den, nrm);
+  const int ubase = 2 * NX * (T + 1);
+  for (int b = 0; b < T; ++b) ls_block<2 * NU>(z, ubase + 2 * NU * b, Cr, jj, num, den, nrm);
+  num = rowsum<16>(num);
+  den = rowsum<16>(den);
+  nrm = rowsum<16>(nrm);
+  alpha = -num / den;                                  // mpc.py:121
+  step_norm = fabs(alpha) * sqrt(nrm);                 // mpc.py:122
+}
+
+// ---------------------------------------------------------------------------------------------
+// expm of a column-owned N x N complex matrix: scaling and squaring with the [13/13] Pade
+// approximant (Higham 2005, Alg. 2.3, always degree 13), linear solve by Gauss-Jordan with
+// partial pivoting done with selects (register files cannot be indexed by a run-time row).
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void expm_cols(cplx (&A)[N], int j) {
+  const double theta13 = 5.371920351148152;
+  double cs = 0.0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) cs += sqrt(A[i].re * A[i].re + A[i].im * A[i].im);
+  const double nrm = rowmax<N>(cs);
+  int s = 0;
+  if (finite_d(nrm) && nrm > theta13) s = ilogb(nrm / theta13) + 1;   // NaN/inf: the result is NaN, caught upstream
+  if (s > 60) s = 60;
+  const double sc = ldexp(1.0, -s);
+#pragma unroll
+  for (int i = 0; i < N; ++i) A[i] = cscale(A[i], sc);
+
+  const double b[14] = {64764752532480000.0, 32382376266240000.0, 7771770303897600.0, 1187353796428800.0,
+                        129060195264000.0,   10559470521600.0,    670442572800.0,     33522128640.0,
+                        1323241920.0,        40840800.0,          960960.0,           16380.0,
+                        182.0,               1.0};
+  cplx A2[N], A4[N], A6[N], W[N], Um[N], Vm[N];
+  matmul_cols<N>(A2, A, A);
+  matmul_cols<N>(A4, A2, A2);
+  matmul_cols<N>(A6, A4, A2);
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    W[i] = mk(b[13] * A6[i].re + b[11] * A4[i].re + b[9] * A2[i].re, b[13] * A6[i].im + b[11] * A4[i].im + b[9] * A2[i].im);
+  matmul_cols<N>(Vm, A6, W);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const double id = (i == j) ? b[1] : 0.0;
+    W[i] = mk(Vm[i].re + b[7] * A6[i].re + b[5] * A4[i].re + b[3] * A2[i].re + id,
+              Vm[i].im + b[7] * A6[i].im + b[5] * A4[i].im + b[3] * A2[i].im);
+  }
+  matmul_cols<N>(Um, A, W);                                   // U = A (A6 (b13 A6 + b11 A4 + b9 A2) + b7 A6 + ... + b1 I)
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    W[i] = mk(b[12] * A6[i].re + b[10] * A4[i].re + b[8] * A2[i].re, b[12] * A6[i].im + b[10] * A4[i].im + b[8] * A2[i].im);
+  matmul_cols<N>(Vm, A6, W);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const double id = (i == j) ? b[0] : 0.0;
+    Vm[i] = mk(Vm[i].re + b[6] * A6[i].re + b[4] * A4[i].re + b[2] * A2[i].re + id,
+               Vm[i].im + b[6] * A6[i].im + b[4] * A4[i].im + b[2] * A2[i].im);
+  }
+  // solve (V - U) X = (V + U)
+  cplx Qm[N], Pm[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    Qm[i] = csub(Vm[i], Um[i]);
+    Pm[i] = cadd(Vm[i], Um[i]);
+  }
+  static_for<0, N>([&](auto kk) {
+    constexpr int k = decltype(kk)::value;
+    cplx ck[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) ck[i] = bcast<k>(Qm[i]);      // pivot column, replicated
+    int piv = k;
+    double best = ck[k].re * ck[k].re + ck[k].im * ck[k].im;
+#pragma unroll
+    for (int i = k + 1; i < N; ++i) {
+      const double mag = ck[i].re * ck[i].re + ck[i].im * ck[i].im;
+      if (mag > best) { best = mag; piv = i; }
+    }
+#pragma unroll
+    for (int i = k + 1; i < N; ++i) {
+      const bool sw = (piv == i);
+      const cplx q_i = Qm[i], p_i = Pm[i], c_i = ck[i];
+      Qm[i] = csel(sw, Qm[k], q_i);
+      Pm[i] = csel(sw, Pm[k], p_i);
+      ck[i] = csel(sw, ck[k], c_i);
+      Qm[k] = csel(sw, q_i, Qm[k]);
+      Pm[k] = csel(sw, p_i, Pm[k]);
+      ck[k] = csel(sw, c_i, ck[k]);
+    }
+    const double den = 1.0 / (ck[k].re * ck[k].re + ck[k].im * ck[k].im);
+    const cplx pinv = mk(ck[k].re * den, -ck[k].im * den);
+    Qm[k] = cmul(Qm[k], pinv);
+    Pm[k] = cmul(Pm[k], pinv);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      if (i != k) {
+        cmac(Qm[i], cneg(ck[i]), Qm[k]);
+        cmac(Pm[i], cneg(ck[i]), Pm[k]);
+      }
+    }
+  });
+  // undo the scaling: square s times (s differs between the four rows of the wave)
+  for (int it = 0; __any(it < s); ++it) {
+    cplx X2[N];
+    matmul_cols<N>(X2, Pm, Pm);
+    const bool on = it < s;
+#pragma unroll
+    for (int i = 0; i < N; ++i) Pm[i] = csel(on, X2[i], Pm[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) A[i] = Pm[i];
+}
+
+// y_j = sum_i M[i][j] v_i  (M column-owned, v distributed) = (M^T v)_j
+template <int N>
+__device__ __forceinline__ cplx matvec_t(const cplx (&M)[N], cplx v) {
+  cplx y = czero();
+  static_for<0, N>([&](auto ii) {
+    constexpr int i = decltype(ii)::value;
+    cmac_bc<i>(y, v, M[i]);
+  });
+  return y;
+}
+
+// Plant kinds (mirrored in include/m4q.h)
+enum : int { PLANT_NONE = 0, PLANT_HAMILTONIAN = 1, PLANT_GENERATOR = 2 };
+
+// rho+ = U rho U^H with U = expm(-i dt (H0 + sum_k u_k H_k)); x = vec_r(rho)  (experiment.py:190-212).
+// sc: per-instance LDS scratch of at least D*D + 2*NX complex.  One wave per block: __syncthreads
+// is the wave's own LDS fence.
+template <int NX, int NU, int D>
+__device__ __forceinline__ cplx plant_hamiltonian(cplx x, const double (&u)[NU], const GView& H0, const GView& Hk, double dt,
+                                                  cplx* sc, int j, int jj) {
+  static_assert(D * D == NX, "state is a vectorised d x d density matrix");
+  const int jc = j < D ? j : D - 1;
+  cplx G[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    cplx hsum = H0.ld<cplx>(i * D + jc);
+#pragma unroll
+    for (int k = 0; k < NU; ++k) cmac_r(hsum, Hk.ld<cplx>((k * D + i) * D + jc), u[k]);
+    G[i] = mk(hsum.im * dt, -hsum.re * dt);              // -i dt H
+  }
+  expm_cols<D>(G, jc);
+  cplx* Us = sc;             // [D][D]
+  cplx* xs = sc + D * D;     // [NX]
+  cplx* Ms = xs + NX;        // [NX]
+  if (jj < D) {
+#pragma unroll
+    for (int a = 0; a < D; ++a) Us[a * D + jj] = G[a];
+  }
+  if (jj < NX) xs[jj] = x;
+  __syncthreads();
+  const int a = j / D, e = j - (j / D) * D;
+  cplx m = czero();
+#pragma unroll
+  for (int c = 0; c < D; ++c) cmac(m, Us[a * D + c], xs[c * D + e]);      // (U rho)[a][e]
+  if (jj < NX) Ms[jj] = m;
+  __syncthreads();
+  cplx out = czero();
+#pragma unroll
+  for (int c = 0; c < D; ++c) cmac_cj(out, Us[e * D + c], Ms[a * D + c]); // sum_c (U rho)[a][c] conj(U[e][c])
+  __syncthreads();
+  return out;
+}
+
+// x+ = expm(dt (L0 + sum_k u_k L_k)) x for a general generator on vec_r(rho).  The lane owns
+// ROW j of L, i.e. column j of L^T; expm(L^T) = expm(L)^T, so it ends up with row j of the propagator.
+template <int NX, int NU>
+__device__ __forceinline__ cplx plant_generator(cplx x, const double (&u)[NU], const GView& L0, const GView& Lk, double dt,
+                                                int j) {
+  cplx G[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    cplx l = L0.ld<cplx>(j * NX + i);
+#pragma unroll
+    for (int k = 0; k < NU; ++k) cmac_r(l, Lk.ld<cplx>((k * NX + j) * NX + i), u[k]);
+    G[i] = cscale(l, dt);
+  }
+  expm_cols<NX>(G, j);
+  return matvec_t<NX>(G, x);
+}
+
+}  // namespace m4q

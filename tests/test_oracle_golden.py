@@ -1,0 +1,119 @@
+"""Pins the CPU oracle (oracle/m4q_oracle.py) against outputs of the reference's own files
+(tests/golden/*.npz, made by tests/golden/make_golden.py) and against the reference's one
+known-answer test for this path (tests/test_mpc4quantum.py:147-188)."""
+import numpy as np
+import pytest
+
+from oracle import m4q_oracle as orc
+
+TOL = 1e-12
+SYSTEMS = [("qubit", 1), ("qubit", 2), ("transmon", 1), ("transmon", 2), ("coupled", 1)]
+DIMS = {"qubit": (2, 1), "transmon": (3, 2), "coupled": (4, 3)}
+
+
+@pytest.mark.parametrize("order", [1, 2, 3])
+@pytest.mark.parametrize("m", [1, 2, 3])
+def test_library_tables(golden, order, m):
+    g = golden("library_tables")
+    key = "o%d_m%d" % (order, m)
+    powers = np.vstack(orc.create_power_list(order, m))
+    assert np.array_equal(powers, g[key + "_powers"])
+    assert orc.size_of_library(order, m) == int(g[key + "_size"])
+    dpow, dcoef = orc.diff_tables(order, m)
+    assert np.array_equal(np.stack(dcoef), g[key + "_dcoef"])
+    u = g[key + "_u"]
+    assert np.allclose(orc.monomials(u, orc.create_power_list(order, m)), g[key + "_lib"], rtol=0, atol=TOL)
+    dlib = np.stack([orc.monomials(u, dp) for dp in dpow])
+    assert np.allclose(dlib, g[key + "_dlib"], rtol=0, atol=TOL)
+
+
+def test_krtimes(golden):
+    g = golden("library_tables")
+    assert np.allclose(orc.krtimes(g["kr_a"], g["kr_b"]), g["kr_out"], rtol=0, atol=TOL)
+    # probe recorded in SURVEY.md 8(a8)
+    out = orc.krtimes(np.array([[10.], [20.]]), np.array([[1.], [2.], [3.]]))
+    assert out.reshape(-1).tolist() == [10, 20, 30, 20, 40, 60]
+    with pytest.raises(ValueError):
+        orc.krtimes(np.ones((2, 3)), np.ones((2, 4)))
+
+
+@pytest.mark.parametrize("name,order", SYSTEMS)
+def test_discretize(golden, name, order):
+    g = golden("discretize")
+    out = orc.discretize_homogeneous(list(g[name + "_A_cts"]), float(g[name + "_dt"]), order)
+    assert np.abs(out - g["%s_o%d" % (name, order)]).max() <= TOL
+
+
+def test_discretize_known_answer():
+    """Order 1, dt 1: [I + A | N_1 | N_2] (reference tests/test_mpc4quantum.py:147-188)."""
+    sx = np.array([[0, 1], [1, 0]], dtype=complex)
+    sy = np.array([[0, -1j], [1j, 0]], dtype=complex)
+    basis = [np.outer(np.eye(2)[i], np.eye(2)[j]) for i in range(2) for j in range(2)]
+    l1 = [orc.vectorize_me(op, basis) for op in (0 * sx, sx)]
+    l2 = [orc.vectorize_me(op, basis) for op in (0 * sy, sy)]
+    z = np.zeros((4, 4))
+    ops = [np.block([[l1[0], z], [z, l2[0]]]), np.block([[l1[1], z], [z, z]]), np.block([[z, z], [z, l2[1]]])]
+    out = orc.discretize_homogeneous(ops, 1, 1)
+    expect = np.hstack([ops[0] + np.identity(8), ops[1], ops[2]])
+    assert np.isclose(out, expect).all()
+
+
+def test_vectorize_me_closed_form():
+    rng = np.random.default_rng(0)
+    for d in (2, 3, 4):
+        M = rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))
+        H = M + M.conj().T
+        basis = [np.outer(np.eye(d)[i], np.eye(d)[j]) for i in range(d) for j in range(d)]
+        assert np.abs(orc.vectorize_me(H, basis) - orc.liouvillian_ij(H)).max() < 1e-13
+
+
+@pytest.mark.parametrize("name,order", SYSTEMS)
+def test_linearize(golden, name, order):
+    g = golden("linearize")
+    key = "%s_o%d" % (name, order)
+    d, m = DIMS[name]
+    n = d * d
+    model = g[key + "_model"]
+    dm = orc.OracleDMDc(n, n, model.shape[1] - n, model)
+    wm = orc.OracleWrapModel(*dm.get_discrete(), m, order)
+    xs, us = g[key + "_xs"], g[key + "_us"]
+    A_ls, B_ls, D_ls = wm.get_model_along_traj(xs, us, np.arange(us.shape[1]))
+    assert np.abs(np.stack(A_ls) - g[key + "_A"]).max() <= TOL
+    assert np.abs(np.stack(B_ls) - g[key + "_B"]).max() <= TOL
+    assert np.abs(np.stack(D_ls) - g[key + "_D"]).max() <= TOL
+    assert np.abs(wm.lift_u(us) - g[key + "_liftu"]).max() <= TOL
+    f = np.hstack([wm.f(xs[:, i], us[:, i]) for i in range(us.shape[1])])
+    assert np.abs(f - g[key + "_f"]).max() <= TOL
+    ux = orc.krtimes(wm.lift_u(us[:, :1]), xs[:, :1])
+    assert np.abs(dm.predict(xs[:, :1], ux) - g[key + "_predict"]).max() <= TOL
+    # identities recorded in SURVEY.md 3.2: f == A_t x and Delta == -B_t u
+    for i in range(us.shape[1]):
+        assert np.abs(f[:, i] - A_ls[i] @ xs[:, i]).max() < 1e-13
+        assert np.abs(D_ls[i][:, 0] + B_ls[i] @ us[:, i]).max() < 1e-13
+
+
+def test_wrapmodel_dimension_check():
+    with pytest.raises(ValueError):
+        orc.OracleWrapModel(np.eye(4), np.zeros((4, 12)), 1, 1)
+
+
+@pytest.mark.parametrize("name,order", SYSTEMS)
+@pytest.mark.parametrize("tag", ["free", "sat"])
+def test_lqr_quad_program(golden, name, order, tag):
+    g = golden("lqr")
+    key = "%s_o%d" % (name, order)
+    k2 = key + "_" + tag
+    A_ls, B_ls = list(g[key + "_A"]), list(g[key + "_B"])
+    T = len(A_ls)
+    m = B_ls[0].shape[1]
+    Q_ls = [g[key + "_Q"]] * T + [g[key + "_Qf"]]
+    R_ls = [float(g[k2 + "_r"]) * np.identity(m)] * T
+    X, U, cost, gains = orc.lqr_quad_program(g[key + "_x0"], g[key + "_X_bm"], g[key + "_U_bm"], Q_ls, R_ls,
+                                             A_ls, B_ls, None, float(g[k2 + "_sat"]), None)
+    scale = max(1.0, np.abs(g[k2 + "_gains"]).max())
+    assert np.abs(np.stack(gains) - g[k2 + "_gains"]).max() <= 1e-10 * scale
+    assert np.abs(X - g[k2 + "_X"]).max() <= 1e-10
+    assert np.abs(U - g[k2 + "_U"]).max() <= 1e-10
+    assert abs(cost - float(g[k2 + "_cost"])) <= 1e-10 * max(1.0, abs(cost))
+    if tag == "sat":
+        assert np.isclose(np.abs(U).max(), float(g[k2 + "_sat"]))     # the bound is active in this fixture
