@@ -141,7 +141,9 @@ enum m4q_field {
   M4Q_F_CODES = 11,     /* [B] i32 */
   M4Q_F_STEPS_DONE = 12,/* [B] i32 */
   M4Q_F_QP_SOLVES = 13, /* [B][n_steps] i32 */
-  M4Q_F_COUNT = 14
+  M4Q_F_X_GUESS = 14,   /* [B][T+1][n] c   SQP guess carried between MPC steps (mpc.py:141,228,271) */
+  M4Q_F_U_GUESS = 15,   /* [B][T][m] r     together with XS/US/CODES this is the whole resumable state */
+  M4Q_F_COUNT = 16
 };
 
 /* device < 0: keep the current device */

@@ -1,0 +1,15 @@
+"""mpc4quantum_amd - MI355X-native engine for the MPC hot path of andgoldschmidt/MPC4quantum.
+
+Same public names as the reference package (mpc4quantum/__init__.py:3-7 star-exports experiment,
+linearize, model, mpc, vectorize), backed by hand-written HIP kernels in libm4q_hip.so."""
+from .experiment import Experiment, LExperiment, QExperiment, plant_step_batch  # noqa: F401
+from .library import (create_library, create_library_from_list, create_power_list, diff_library, krtimes,  # noqa: F401
+                      multinomial_powers, size_of_library)
+from .linearize import WrapModel  # noqa: F401
+from .model import DMDc  # noqa: F401
+from .mpc import StepClock, iqp_line_search, mpc, mpc_batch, shift_guess, val_to_str  # noqa: F401
+from .optimize import quad_program, quad_program_batch  # noqa: F401
+from .session import EnsembleSession  # noqa: F401
+from .vectorize import discretize_homogeneous, liouvillian, vectorize_me  # noqa: F401
+
+__version__ = "0.1.0"

@@ -111,7 +111,7 @@ struct m4q_session {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int grid = 1;
   DevBuf f[M4Q_F_COUNT];
-  DevBuf Cq, Cqf, Cr, Xg, Ug, wsXo, wsUo, wsG;
+  DevBuf Cq, Cqf, Cr, wsXo, wsUo, wsG;
   size_t fbytes[M4Q_F_COUNT]{};
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
   double ms_total = 0.0;
@@ -188,6 +188,8 @@ int m4q_session_create(const m4q_problem* p, int32_t B, int32_t device, m4q_sess
   fb[M4Q_F_CODES] = (size_t)B * 4;
   fb[M4Q_F_STEPS_DONE] = (size_t)B * 4;
   fb[M4Q_F_QP_SOLVES] = (size_t)B * ns * 4;
+  fb[M4Q_F_X_GUESS] = (size_t)B * (T + 1) * n * C;
+  fb[M4Q_F_U_GUESS] = (size_t)B * T * m * 8;
   int rc = 0;
   for (int i = 0; i < M4Q_F_COUNT && !rc; ++i) rc = s->f[i].alloc(fb[i]);
   // resident grid: as many workgroups as the device holds at once (persistent, quad-strided)
@@ -199,8 +201,6 @@ int m4q_session_create(const m4q_problem* p, int32_t B, int32_t device, m4q_sess
   long resident = (long)per_cu * prop.multiProcessorCount;
   s->grid = (int)(nquads < resident ? nquads : resident);
   const size_t rows = (size_t)s->grid * 4;
-  if (!rc) rc = s->Xg.alloc((size_t)B * (T + 1) * n * C);
-  if (!rc) rc = s->Ug.alloc((size_t)B * T * m * 8);
   if (!rc) rc = s->wsXo.alloc(rows * (T + 1) * n * C);
   if (!rc) rc = s->wsUo.alloc(rows * T * m * 8);
   if (!rc) rc = s->wsG.alloc(rows * T * (n + 1) * m * C);
@@ -322,7 +322,7 @@ int m4q_session_run(m4q_session* s, int32_t step_begin, int32_t step_end) {
   if (p.plant_kind == M4Q_PLANT_NONE) { a.op0 = a.Q; a.ops = a.Q; a.op0_stride = a.ops_stride = 0; }
   a.xs = (cplx*)s->f[M4Q_F_XS].p; a.us = (double*)s->f[M4Q_F_US].p;
   a.codes = (int*)s->f[M4Q_F_CODES].p; a.steps_done = (int*)s->f[M4Q_F_STEPS_DONE].p; a.qp_solves = (int*)s->f[M4Q_F_QP_SOLVES].p;
-  a.Xg = (cplx*)s->Xg.p; a.Ug = (double*)s->Ug.p;
+  a.Xg = (cplx*)s->f[M4Q_F_X_GUESS].p; a.Ug = (double*)s->f[M4Q_F_U_GUESS].p;
   a.ws_Xo = (cplx*)s->wsXo.p; a.ws_Uo = (double*)s->wsUo.p; a.ws_gains = (cplx*)s->wsG.p;
   if (step_begin == 0) {
     HIP_TRY(hipMemsetAsync(s->f[M4Q_F_QP_SOLVES].p, 0, s->fbytes[M4Q_F_QP_SOLVES], s->stream));
@@ -376,7 +376,7 @@ int m4q_session_info(const m4q_session* s, int64_t* hbm_bytes, int32_t* grid, in
   if (!s) return fail(M4Q_E_BADARG, "m4q_session_info: null session");
   int64_t tot = 0;
   for (int i = 0; i < M4Q_F_COUNT; ++i) tot += (int64_t)s->f[i].bytes;
-  tot += (int64_t)(s->Xg.bytes + s->Ug.bytes + s->wsXo.bytes + s->wsUo.bytes + s->wsG.bytes);
+  tot += (int64_t)(s->wsXo.bytes + s->wsUo.bytes + s->wsG.bytes);
   if (hbm_bytes) *hbm_bytes = tot;
   if (grid) *grid = s->grid;
   if (lds_bytes) *lds_bytes = (int32_t)s->shape->mpc_lds_bytes();

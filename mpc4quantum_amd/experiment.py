@@ -1,0 +1,119 @@
+"""Plants.  `Experiment` keeps the reference's duck type (mpc4quantum/experiment.py:8-49: lift, proj,
+simulate).  `QExperiment` is the state-preparation plant of experiment.py:175-212 with the ODE
+  d rho/dt = -i [H0 + sum_k u_k(t) H_k, rho]
+solved exactly over each held-control interval by the HIP Pade-13 kernel (m4q_plant_step_batch)
+instead of qutip.mesolve.  `mpc()` recognises it and keeps the whole closed loop on the GPU."""
+from abc import ABC, abstractmethod
+
+import numpy as np
+
+from . import _lib
+
+
+class Experiment(ABC):
+    def __init__(self):
+        self.ts = None
+        self.us = None
+        self.xs = None
+
+    @abstractmethod
+    def f(self, t, x, u):
+        """Time derivative of the state."""
+
+    @staticmethod
+    def lift(x):
+        return x
+
+    @staticmethod
+    def proj(z):
+        return z
+
+    @abstractmethod
+    def simulate(self, x0, ts, us):
+        """States at all times in ts, shape (n, len(ts))."""
+
+
+def _as_array(op):
+    return np.asarray(op.full() if hasattr(op, "full") else op, dtype=np.complex128)
+
+
+def plant_step_batch(x, u, op0, ops, dt, kind=_lib.PLANT_HAMILTONIAN):
+    """x [B,n], u [B,m], op0 [B|1,k,k] (or [k,k]), ops [B|1,m,k,k] (or [m,k,k]) -> x_next [B,n]."""
+    x = np.ascontiguousarray(x, dtype=np.complex128)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    Bn, n = x.shape
+    m = u.shape[1]
+    op0 = np.ascontiguousarray(op0, dtype=np.complex128)
+    ops = np.ascontiguousarray(ops, dtype=np.complex128)
+    per = 1 if (op0.ndim == 3 and op0.shape[0] > 1) else 0
+    out = np.empty_like(x)
+    L = _lib.lib()
+    _lib.check(L.m4q_plant_step_batch(Bn, n, m, int(kind), float(dt), _lib.cbuf(x)[1], _lib.rbuf(u)[1], _lib.cbuf(op0)[1],
+                                      _lib.cbuf(ops)[1], per, out.ctypes.data_as(_lib._dp)))
+    return out
+
+
+class QExperiment(Experiment):
+    """Closed-system plant: H0 and H1_list are d x d Hermitian (ndarray or qutip.Qobj)."""
+
+    plant_kind = _lib.PLANT_HAMILTONIAN
+
+    def __init__(self, H0, H1_list):
+        super().__init__()
+        self.H0 = _as_array(H0)
+        self.H1_list = [_as_array(h) for h in H1_list]
+        self._sigma = 0
+
+    def operators(self):
+        return self.H0, np.stack(self.H1_list)
+
+    def f(self, t, x, u):
+        d = self.H0.shape[0]
+        H = self.H0 + sum(h * uk for h, uk in zip(self.H1_list, np.reshape(u, -1)))
+        rho = np.reshape(x, (d, d))
+        return (-1j * (H @ rho - rho @ H)).reshape(-1)
+
+    def set_sigma(self, sigma):
+        self._sigma = sigma
+
+    def simulate(self, x0, ts, us):
+        """Piecewise-constant control (interp1d kind='previous', mpc.py:258): `us` is a callable of
+        time or an (m, len(ts)) array whose column i is held on [ts[i], ts[i+1])."""
+        ts = np.asarray(ts, dtype=float)
+        m = len(self.H1_list)
+        x = np.reshape(np.asarray(x0, dtype=np.complex128), -1)
+        cols = [x]
+        for i in range(len(ts) - 1):
+            u = np.reshape(us(ts[i]) if callable(us) else np.atleast_2d(us)[:, i], -1)[:m]
+            x = plant_step_batch(x[None], np.real(u)[None], self.H0, np.stack(self.H1_list), ts[i + 1] - ts[i])[0]
+            cols.append(x)
+        self.ts, self.us = ts, us
+        self.xs = np.stack(cols, axis=1)
+        if self._sigma:
+            noise = np.random.randn(*self.xs.shape) + 1j * np.random.randn(*self.xs.shape)
+            return self.xs + noise * self._sigma
+        return self.xs
+
+
+class LExperiment(QExperiment):
+    """Open-system plant: x' = (L0 + sum_k u_k L_k) x with n x n generators on vec_r(rho)."""
+
+    plant_kind = _lib.PLANT_GENERATOR
+
+    def f(self, t, x, u):
+        L = self.H0 + sum(h * uk for h, uk in zip(self.H1_list, np.reshape(u, -1)))
+        return L @ np.reshape(x, -1)
+
+    def simulate(self, x0, ts, us):
+        ts = np.asarray(ts, dtype=float)
+        m = len(self.H1_list)
+        x = np.reshape(np.asarray(x0, dtype=np.complex128), -1)
+        cols = [x]
+        for i in range(len(ts) - 1):
+            u = np.reshape(us(ts[i]) if callable(us) else np.atleast_2d(us)[:, i], -1)[:m]
+            x = plant_step_batch(x[None], np.real(u)[None], self.H0, np.stack(self.H1_list), ts[i + 1] - ts[i],
+                                 _lib.PLANT_GENERATOR)[0]
+            cols.append(x)
+        self.ts, self.us = ts, us
+        self.xs = np.stack(cols, axis=1)
+        return self.xs

@@ -468,12 +468,13 @@ class OracleQExperiment:
 
 
 def mpc(x0, dim_u, order, X_targ, U_targ, clock, experiment, model, Q, R, Qf, sat=None, du=None, max_iter=100,
-        exit_condition=None, warm_start=True, qp_mode="qp", count=None):
+        exit_condition=None, warm_start=True, qp_mode="qp", count=None, trace=None):
     """Receding-horizon loop restating mpc.py:128-304 for measure_freq == 1, streaming == False,
     with ``quad_program`` being the Riccati solver above (qp_mode "qp") or the lqr.py restatement
     (qp_mode "lqr").  Keeps the quirks: u_prev from U_ref at steps 0 and 1 (:185), applied control
     U_opt[:,0] (:250), target window lag (:276-277), exit codes 0/1/3 and the dropped last entry
-    (:294-304).  ``count`` (a list) receives the number of QP solves per MPC step."""
+    (:294-304).  ``count`` (a list) receives the number of QP solves per MPC step; ``trace`` (a list) receives
+    (X_guess, U_guess) as they stand when each MPC step starts."""
     exit_code = 0
     T = clock.horizon
     lift_x0 = np.asarray(experiment.lift(x0), dtype=complex)
@@ -491,6 +492,8 @@ def mpc(x0, dim_u, order, X_targ, U_targ, clock, experiment, model, Q, R, Qf, sa
     for step in range(clock.n_steps):
         n_iter = 0
         done = False
+        if trace is not None:
+            trace.append((X_guess.copy(), U_guess.copy()))
         while not done and n_iter < max_iter:
             A_ls, B_ls, D_ls = wm.get_model_along_traj(X_guess, U_guess, clock.ts_horizon(step))
             u_prev = us[step - 1] if step > 1 else U_ref[:, 0].reshape(-1, 1)
@@ -528,6 +531,8 @@ def mpc(x0, dim_u, order, X_targ, U_targ, clock, experiment, model, Q, R, Qf, sa
         if exit_condition is not None and exit_condition(xs[step + 1], xs[step], us[step]):
             exit_code = 1
             break
+    if trace is not None:
+        trace.append((X_guess.copy(), U_guess.copy()))
     if exit_code == 0:
         clock.set_endsim(step + 1)
         return [np.vstack(xs[:step + 2]).T, np.vstack(us[:step + 1]).T], model, exit_code
@@ -538,7 +543,7 @@ def mpc(x0, dim_u, order, X_targ, U_targ, clock, experiment, model, Q, R, Qf, sa
 
 
 def mpc_batch(x0s, A_models, dim_u, order, X_targ, U_targ, dt, horizon, n_steps, H0s, H_list, Q, R, Qf,
-              sat, du, max_iter=100, warm_start=True, qp_mode="qp"):
+              sat, du, max_iter=100, warm_start=True, qp_mode="qp", trace=None):
     """Loop ``mpc`` over an ensemble.  x0s (B, n); A_models (B or 1, n, n(1+P)); H0s (B or 1, d, d).
     Returns xs (B, n, n_steps+1) (NaN-padded after an early exit), us (B, m, n_steps),
     exit codes (B,), QP solves per MPC step (B, n_steps)."""
@@ -556,8 +561,11 @@ def mpc_batch(x0s, A_models, dim_u, order, X_targ, U_targ, dt, horizon, n_steps,
         exp = OracleQExperiment(H0s[b if H0s.shape[0] > 1 else 0], H_list)
         clock = OracleClock(dt, horizon, n_steps)
         cnt = []
+        tr = [] if trace is not None else None
         (xs, us), _, code = mpc(x0s[b], dim_u, order, X_targ, U_targ, clock, exp, model, Q, R, Qf, sat=sat, du=du,
-                                max_iter=max_iter, warm_start=warm_start, qp_mode=qp_mode, count=cnt)
+                                max_iter=max_iter, warm_start=warm_start, qp_mode=qp_mode, count=cnt, trace=tr)
+        if trace is not None:
+            trace.append(tr)
         xs_out[b, :, :xs.shape[1]] = xs
         if us is not None:
             us_out[b, :, :us.shape[1]] = us

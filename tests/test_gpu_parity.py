@@ -1,0 +1,491 @@
+"""GPU parity tests (-m gpu): every HIP entry point, called through the C ABI, against
+(a) outputs of the reference's own files (tests/golden/*.npz) and (b) the CPU oracle on the same
+seeded inputs.  fp64 tolerances: 1e-10 relative for one QP solve / one MPC step,
+1e-8 after a 20-step closed loop."""
+import numpy as np
+import pytest
+
+import mpc4quantum_amd as m4q
+from mpc4quantum_amd import _lib, configs
+from mpc4quantum_amd import lqr as m4q_lqr
+from oracle import m4q_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+SYSTEMS = [("qubit", 1), ("qubit", 2), ("transmon", 1), ("transmon", 2), ("coupled", 1)]
+DIMS = {"qubit": (2, 1), "transmon": (3, 2), "coupled": (4, 3)}
+
+
+def rel(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / max(1.0, np.abs(np.asarray(b)).max())
+
+
+def test_device_present():
+    assert _lib.device_count() >= 1
+
+
+# ---------------------------------------------------------------- linearisation
+@pytest.mark.parametrize("name,order", SYSTEMS)
+def test_linearize_vs_reference_golden(golden, name, order):
+    g = golden("linearize")
+    key = "%s_o%d" % (name, order)
+    d, m = DIMS[name]
+    n = d * d
+    model = g[key + "_model"]
+    dm = m4q.DMDc(n, n, model.shape[1] - n, model)
+    wm = m4q.WrapModel(*dm.get_discrete(), m, order)
+    xs, us = g[key + "_xs"], g[key + "_us"]
+    A_ls, B_ls, D_ls = wm.get_model_along_traj(xs, us, np.arange(us.shape[1]))
+    assert rel(np.stack(A_ls), g[key + "_A"]) <= 1e-13
+    assert rel(np.stack(B_ls), g[key + "_B"]) <= 1e-13
+    assert rel(np.stack(D_ls), g[key + "_D"]) <= 1e-13
+    assert D_ls[0].shape == (n, 1)
+    assert rel(wm.df_dx(xs[:, 2], us[:, 2], 0), g[key + "_A"][2]) <= 1e-13
+    assert rel(wm.df_du(xs[:, 2], us[:, 2], 0), g[key + "_B"][2]) <= 1e-13
+
+
+def test_linearize_batch_ragged_and_per_instance_models():
+    # 7 trajectories (not a multiple of 4), per-instance models through the raw C entry point
+    rng = np.random.default_rng(5)
+    p = configs.build(3, batch=7, order=2)
+    n, m, T = 9, 2, 5
+    X = rng.standard_normal((7, T, n)) + 1j * rng.standard_normal((7, T, n))
+    U = 0.3 * rng.standard_normal((7, T, m))
+    A = np.empty((7, T, n, n), dtype=complex)
+    Bm = np.empty((7, T, n, m), dtype=complex)
+    D = np.empty((7, T, n), dtype=complex)
+    L = _lib.lib()
+    _lib.check(L.m4q_linearize_batch(7, n, m, 2, T, _lib.cbuf(p["models"])[1], 1, _lib.cbuf(X)[1], _lib.rbuf(U)[1],
+                                     A.ctypes.data_as(_lib._dp), Bm.ctypes.data_as(_lib._dp), D.ctypes.data_as(_lib._dp)))
+    for b in range(7):
+        mod = p["models"][b]
+        wm = orc.OracleWrapModel(mod[:, :n], mod[:, n:], m, 2)
+        Ao, Bo, Do = wm.get_model_along_traj(X[b].T, U[b].T, np.arange(T))
+        assert rel(A[b], np.stack(Ao)) <= 1e-13
+        assert rel(Bm[b], np.stack(Bo)) <= 1e-13
+        assert rel(D[b], np.stack(Do)[:, :, 0]) <= 1e-12
+
+
+def test_unsupported_shape_raises():
+    with pytest.raises(_lib.M4qError):
+        m4q.WrapModel(np.eye(25), np.zeros((25, 25)), 1, 1).linearize_batch(np.zeros((1, 2, 25)), np.zeros((1, 2, 1)))
+    with pytest.raises(ValueError):
+        m4q.WrapModel(np.eye(4), np.zeros((4, 12)), 1, 1)
+
+
+# ---------------------------------------------------------------- QP / Riccati
+@pytest.mark.parametrize("name,order", SYSTEMS)
+@pytest.mark.parametrize("tag", ["free", "sat"])
+def test_lqr_mode_vs_reference_golden(golden, name, order, tag):
+    """M4Q_QP_REF_LQR against outputs of the reference's lqr.quad_program."""
+    g = golden("lqr")
+    key = "%s_o%d" % (name, order)
+    k2 = key + "_" + tag
+    A_ls, B_ls = list(g[key + "_A"]), list(g[key + "_B"])
+    T = len(A_ls)
+    mdim = B_ls[0].shape[1]
+    Q_ls = [g[key + "_Q"]] * T + [g[key + "_Qf"]]
+    R_ls = [float(g[k2 + "_r"]) * np.identity(mdim)] * T
+    X, U, cost, gains = m4q_lqr.quad_program(g[key + "_x0"], g[key + "_X_bm"], g[key + "_U_bm"], Q_ls, R_ls, A_ls, B_ls,
+                                             None, float(g[k2 + "_sat"]), None)
+    assert rel(np.stack(gains), g[k2 + "_gains"]) <= 1e-10
+    assert rel(X, g[k2 + "_X"]) <= 1e-10
+    assert rel(U, g[k2 + "_U"]) <= 1e-10
+    assert abs(cost - float(g[k2 + "_cost"])) <= 1e-10 * max(1.0, abs(cost))
+
+
+def _random_ltv(rng, n, m, T, Bn):
+    A = np.eye(n) + 0.3 * (rng.standard_normal((Bn, T, n, n)) + 1j * rng.standard_normal((Bn, T, n, n))) / np.sqrt(n)
+    Bm = 0.5 * (rng.standard_normal((Bn, T, n, m)) + 1j * rng.standard_normal((Bn, T, n, m)))
+    D = 0.05 * (rng.standard_normal((Bn, T, n)) + 1j * rng.standard_normal((Bn, T, n)))
+    x0 = rng.standard_normal((Bn, n)) + 1j * rng.standard_normal((Bn, n))
+    Xb = 0.5 * (rng.standard_normal((Bn, T + 1, n)) + 1j * rng.standard_normal((Bn, T + 1, n)))
+    Ub = 0.2 * rng.standard_normal((Bn, T, m))
+    Qs = []
+    for _ in range(T + 1):
+        M = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        Qs.append(M @ M.conj().T / n)
+    Rs = []
+    for _ in range(T):
+        M = rng.standard_normal((m, m)) + 1j * rng.standard_normal((m, m))
+        Rs.append(M @ M.conj().T / m + 0.5 * np.eye(m))
+    return A, Bm, D, x0, Xb, Ub, np.stack(Qs), np.stack(Rs)
+
+
+@pytest.mark.parametrize("n,m", [(4, 1), (9, 2), (16, 3)])
+def test_qp_mode_vs_oracle_general(n, m):
+    """Dense complex A_t, time-varying Hermitian Q_t, R_t, ramped targets, Delta, per-instance benchmarks,
+    ragged batch, both with the bounds inactive and active, with and without the du band."""
+    rng = np.random.default_rng(100 + n)
+    T, Bn = 7, 6
+    A, Bm, D, x0, Xb, Ub, Qs, Rs = _random_ltv(rng, n, m, T, Bn)
+    uprev = 0.1 * rng.standard_normal((Bn, m))
+    for sat, du in ((1e3, None), (0.3, None), (0.6, 0.2)):
+        X, U, cost, gains = m4q.quad_program_batch(x0, Xb, Ub, Qs, Rs, A, Bm, D, uprev if du else None, sat, du)
+        for b in range(Bn):
+            Xo, Uo, co, go = orc.quad_program(x0[b], Xb[b].T, Ub[b].T, list(Qs), list(Rs), list(A[b]), list(Bm[b]),
+                                              list(D[b]), uprev[b] if du else None, sat, du)
+            assert rel(gains[b], np.stack([gk.T for gk in go])) <= 1e-9
+            assert rel(X[b].T, Xo) <= 1e-9
+            assert rel(U[b].T, Uo) <= 1e-9
+            assert abs(cost[b] - co) <= 1e-9 * max(1.0, abs(co))
+        if du:
+            assert np.all(np.abs(U[:, 0, :] - uprev) <= du + 1e-15)
+        assert np.abs(U).max() <= sat + 1e-15
+
+
+def test_qp_mode_vs_independent_kkt():
+    """Unconstrained case against a dense KKT solve (real controls) of the QP stated at optimize.py:27-41,54.
+    lqr.py takes the real part of a complex gain (lqr.py:75-76), which is the real-control optimum when the
+    model preserves Hermiticity, as every vectorised-Liouvillian model does: use such a problem."""
+    rng = np.random.default_rng(7)
+    p = configs.build(3, batch=2, order=2)
+    n, m, T = 9, 2, 6
+    A, Bm, D, x0 = [], [], [], []
+    for b in range(2):
+        mod = p["models"][b]
+        wm = orc.OracleWrapModel(mod[:, :n], mod[:, n:], m, 2)
+        rhos = []
+        for _ in range(T + 1):
+            M = rng.standard_normal((3, 3)) + 1j * rng.standard_normal((3, 3))
+            r = M @ M.conj().T
+            rhos.append((r / np.trace(r).real).reshape(-1))
+        xg = np.stack(rhos, axis=1)
+        ug = 0.4 * rng.standard_normal((m, T))
+        Ao, Bo, Do = wm.get_model_along_traj(xg, ug, np.arange(T))
+        A.append(np.stack(Ao)); Bm.append(np.stack(Bo)); D.append(np.stack(Do)[:, :, 0]); x0.append(xg[:, 0])
+    A, Bm, D, x0 = np.stack(A), np.stack(Bm), np.stack(D), np.stack(x0)
+    Xb = np.tile(p["X_targ"][:, :T + 1].T[None], (2, 1, 1))
+    Ub = 0.05 * rng.standard_normal((2, T, m))
+    Qs = np.stack([p["Q"]] * T + [3 * p["Q"]]).astype(complex)
+    Rs = np.stack([0.05 * np.eye(m)] * T).astype(complex)
+    X, U, cost, _ = m4q.quad_program_batch(x0, Xb, Ub, Qs, Rs, A, Bm, D, None, 1e6, None)
+    for b in range(2):
+        Xk, Uk = orc.kkt_quad_program(x0[b], Xb[b].T, Ub[b].T, list(Qs), list(Rs), list(A[b]), list(Bm[b]), list(D[b]))
+        assert np.abs(Uk).max() > 1e-2
+        assert rel(U[b].T, Uk) <= 1e-8
+        assert rel(X[b].T, Xk) <= 1e-8
+
+
+def test_quad_program_dropin_signature():
+    """optimize.quad_program(x_init, X_bm, U_bm, Q_ls, R_ls, A_ls, B_ls, Delta_ls, u_prev, sat, du, verbose)."""
+    rng = np.random.default_rng(9)
+    n, m, T = 9, 2, 4
+    A, Bm, D, x0, Xb, Ub, Qs, Rs = _random_ltv(rng, n, m, T, 1)
+    args = (x0[0], Xb[0].T, Ub[0].T, list(Qs), list(Rs), list(A[0]), list(Bm[0]), [d.reshape(-1, 1) for d in D[0]],
+            np.zeros((m, 1)), 0.5, 0.25, False)
+    X, U, obj, aux = m4q.quad_program(*args)
+    Xo, Uo, co, go = orc.quad_program(*args)
+    assert X.shape == (n, T + 1) and U.shape == (m, T) and aux[0].shape == (m, n + 1)
+    assert rel(X, Xo) <= 1e-10 and rel(U, Uo) <= 1e-10 and abs(obj - co) <= 1e-10 * max(1, abs(co))
+    with pytest.raises(TypeError):
+        m4q.quad_program(*args[:9], None, None)
+
+
+def test_nonfinite_inputs_give_nonfinite_cost():
+    rng = np.random.default_rng(3)
+    A, Bm, D, x0, Xb, Ub, Qs, Rs = _random_ltv(rng, 4, 1, 3, 1)
+    A[0, 1, 0, 0] = np.nan
+    _, _, cost, _ = m4q.quad_program_batch(x0, Xb, Ub, Qs, Rs, A, Bm, D, None, 1.0, None)
+    assert not np.isfinite(cost[0])
+
+
+# ---------------------------------------------------------------- plant
+@pytest.mark.parametrize("cfg", [1, 3, 4])
+def test_plant_hamiltonian_vs_expm(cfg):
+    p = configs.build(cfg, batch=5)
+    rng = np.random.default_rng(cfg)
+    d, n, m = p["d"], p["dim_x"], p["dim_u"]
+    rho = []
+    for _ in range(5):
+        M = rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))
+        r = M @ M.conj().T
+        rho.append((r / np.trace(r).real).reshape(-1))
+    x = np.stack(rho)
+    for scale in (1.0, 40.0):      # the large one forces scaling-and-squaring (norm > theta_13)
+        u = scale * p["sat"] * rng.uniform(-1, 1, (5, m))
+        out = m4q.plant_step_batch(x, u, p["plant_op0"], p["plant_ops"], p["dt"])
+        for b in range(5):
+            ref = orc.plant_step(x[b], u[b], p["plant_op0"][0], list(p["plant_ops"][0]), p["dt"])
+            assert rel(out[b], ref) <= 1e-12
+        tr = out.reshape(5, d, d).trace(axis1=1, axis2=2)
+        assert np.abs(tr - 1).max() < 1e-12
+
+
+@pytest.mark.parametrize("d,m", [(2, 1), (3, 2), (4, 3)])
+def test_plant_generator_vs_expm_with_dissipation(d, m):
+    """General generator: Hamiltonian part plus amplitude damping (not unitary), per-instance operators."""
+    rng = np.random.default_rng(10 + d)
+    n = d * d
+    Bn = 5
+    a = np.diag(np.sqrt(np.arange(1, d)), 1).astype(complex)
+
+    def lindblad(c):
+        cd = c.conj().T
+        eye = np.eye(d)
+        return np.kron(c, c.conj()) - 0.5 * (np.kron(cd @ c, eye) + np.kron(eye, (cd @ c).T))
+    L0 = np.stack([m4q.liouvillian((lambda M: M + M.conj().T)(rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))))
+                   + 0.3 * lindblad(a) for _ in range(Bn)])
+    Lk = np.stack([[m4q.liouvillian((lambda M: M + M.conj().T)(rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))))
+                    for _ in range(m)] for _ in range(Bn)])
+    x = rng.standard_normal((Bn, n)) + 1j * rng.standard_normal((Bn, n))
+    for dt in (0.1, 2.5):
+        u = rng.uniform(-1, 1, (Bn, m))
+        out = m4q.plant_step_batch(x, u, L0, Lk, dt, _lib.PLANT_GENERATOR)
+        for b in range(Bn):
+            ref = orc.plant_step_generator(x[b], u[b], L0[b], list(Lk[b]), dt)
+            assert rel(out[b], ref) <= 1e-11
+
+
+def test_qexperiment_simulate_shape_and_values():
+    p = configs.build(3, batch=1)
+    exp = m4q.QExperiment(p["plant_op0"][0], list(p["plant_ops"][0]))
+    ts = np.array([0.0, 0.25, 0.5])
+    us = np.array([[0.3, -0.2, 0.0], [0.1, 0.4, 0.0]])
+    out = exp.simulate(p["x0"][0], ts, us)
+    assert out.shape == (9, 3)
+    x = p["x0"][0]
+    for i in range(2):
+        x = orc.plant_step(x, us[:, i], p["plant_op0"][0], list(p["plant_ops"][0]), 0.25)
+        assert rel(out[:, i + 1], x) <= 1e-12
+
+
+# ---------------------------------------------------------------- closed loop
+def _oracle_batch(p, idx, **kw):
+    models = p["models"] if p["models"].shape[0] == 1 else p["models"][idx]
+    return orc.mpc_batch(p["x0"][idx], models, p["dim_u"], p["order"], p["X_targ"], p["U_targ"], p["dt"], p["horizon"],
+                         p["n_steps"], p["plant_op0"], list(p["plant_ops"][0]), p["Q"], p["R"], p["Qf"], p["sat"], p["du"],
+                         **kw)
+
+
+def _gpu_batch(p, idx, **kw):
+    models = p["models"] if p["models"].shape[0] == 1 else p["models"][idx]
+    clock = m4q.StepClock(p["dt"], p["horizon"], p["n_steps"])
+    return m4q.mpc_batch(p["x0"][idx], models, p["dim_u"], p["order"], p["X_targ"], p["U_targ"], clock, p["plant_op0"],
+                         p["plant_ops"], p["Q"], p["R"], p["Qf"], p["sat"], p["du"], **kw)
+
+
+def _session(p, B, **kw):
+    models = p["models"]
+    return m4q.EnsembleSession(B, p["dim_x"], p["dim_u"], p["order"], p["horizon"], p["n_steps"], p["dt"], p["sat"], p["du"],
+                               model_per_instance=models.shape[0] > 1, target_cols=p["n_steps"] + p["horizon"] + 1, **kw)
+
+
+def _envelope(p, idx, xs, us, eps=1e-14):
+    """How far the ORACLE itself moves when x0 is perturbed by eps (relative): the conditioning of the
+    20-step closed loop.  Controls saturate and the Riccati gains are stiff (R ~ 1e-3/sat^2), so one ulp
+    grows by many orders of magnitude over a run; a free-running comparison can only be asked to stay
+    within that envelope.  Step-by-step parity is checked separately with teacher forcing."""
+    eu = np.zeros(us.shape[2])
+    ex = np.zeros(xs.shape[2])
+    for scale in (1 + eps, 1 - eps, 1 + 7 * eps):
+        q = dict(p)
+        q["x0"] = p["x0"] * scale
+        xs2, us2, _, _ = _oracle_batch(q, idx)
+        eu = np.maximum(eu, np.maximum.accumulate(np.abs(us2 - us).max(axis=(0, 1))))
+        ex = np.maximum(ex, np.maximum.accumulate(np.abs(xs2 - xs).max(axis=(0, 1))))
+    return eu, ex
+
+
+@pytest.mark.parametrize("cfg,order,batch,horizon", [(1, 1, 1, None), (1, 2, 1, None), (2, 1, 6, None), (3, 1, 5, 16),
+                                                      (3, 2, 3, 12), (4, 1, 3, 10)])
+def test_closed_loop_vs_oracle(cfg, order, batch, horizon):
+    """Free-running closed loop, all MPC steps in one launch."""
+    p = configs.build(cfg, batch=batch, order=order, horizon=horizon)
+    idx = np.arange(batch)
+    res = _gpu_batch(p, idx)
+    xs, us, codes, solves = _oracle_batch(p, idx)
+    assert np.array_equal(res["exit_codes"], codes)
+    assert np.array_equal(res["qp_solves"], solves)
+    assert np.all(res["steps_done"] == p["n_steps"])
+    assert rel(res["us"][:, :, 0], us[:, :, 0]) <= 1e-10           # one MPC step (incl. all its SQP iterations)
+    assert rel(res["xs"][:, :, 1], xs[:, :, 1]) <= 1e-10
+    eu, ex = _envelope(p, idx, xs, us)
+    du_k = np.abs(res["us"] - us).max(axis=(0, 1))
+    dx_k = np.abs(res["xs"] - xs).max(axis=(0, 1))
+    assert np.all(du_k <= 1e-9 + 100 * eu), (du_k, eu)
+    assert np.all(dx_k[1:] <= 1e-9 + 100 * ex[1:]), (dx_k, ex)
+    assert np.abs(res["us"]).max() <= p["sat"] * (1 + 1e-15)
+
+
+@pytest.mark.parametrize("cfg,order,batch,horizon", [(1, 2, 1, None), (3, 1, 4, None), (4, 1, 2, 12)])
+def test_closed_loop_stepwise_teacher_forced(cfg, order, batch, horizon):
+    """Every MPC step of the run, started from the ORACLE's state (states, controls, SQP guesses) through the
+    session's checkpoint/restore fields.  The outputs of the step - applied control us[k], next state xs[k+1],
+    QP-solve count - must match to 1e-10 whatever the conditioning of the loop; the shifted SQP
+    guesses (the far end of a stiff 40-step horizon) to 1e-7.  Config 3 runs at its own T = 40."""
+    p = configs.build(cfg, batch=max(batch, 4) if cfg == 3 else batch, order=order, horizon=horizon)
+    idx = np.arange(batch)
+    trace = []
+    models = p["models"] if p["models"].shape[0] == 1 else p["models"][idx]
+    xs, us, codes, solves = orc.mpc_batch(p["x0"][idx], models, p["dim_u"], p["order"], p["X_targ"], p["U_targ"], p["dt"],
+                                          p["horizon"], p["n_steps"], p["plant_op0"], list(p["plant_ops"][0]), p["Q"],
+                                          p["R"], p["Qf"], p["sat"], p["du"], trace=trace)
+    q = dict(p)
+    q["models"] = models
+    ns, T = p["n_steps"], p["horizon"]
+    sess = _session(q, batch)
+    try:
+        sess.load_problem(models, p["x0"][idx], p["X_targ"], p["U_targ"], p["Q"], p["R"], p["Qf"], p["plant_op0"],
+                          p["plant_ops"])
+        xs_t, us_t = np.swapaxes(xs, 1, 2), np.swapaxes(us, 1, 2)          # time-major, as the C ABI holds them
+        worst = 0.0
+        for k in range(ns):
+            if k > 0:
+                st = {"xs": np.zeros_like(xs_t), "us": np.zeros_like(us_t),
+                      "x_guess": np.stack([trace[b][k][0].T for b in range(batch)]),
+                      "u_guess": np.stack([trace[b][k][1].T for b in range(batch)]),
+                      "exit_codes": np.zeros(batch, dtype=np.int32), "steps_done": np.full(batch, k, dtype=np.int32)}
+                st["xs"][:, :k + 1] = xs_t[:, :k + 1]
+                st["us"][:, :k] = us_t[:, :k]
+                sess.restore(st)
+            sess.run(k, k + 1)
+            got = sess.state()
+            assert np.array_equal(sess.download(_lib.F_QP_SOLVES, (batch, ns))[:, k], solves[:, k])
+            errs = [rel(got["us"][:, k], us_t[:, k]), rel(got["xs"][:, k + 1], xs_t[:, k + 1]),
+                    rel(got["x_guess"], np.stack([trace[b][k + 1][0].T for b in range(batch)])),
+                    rel(got["u_guess"], np.stack([trace[b][k + 1][1].T for b in range(batch)]))]
+            worst = max(worst, max(errs))
+            assert max(errs[:2]) <= 1e-10 and max(errs[2:]) <= 1e-7, (k, errs)
+            assert np.all(got["steps_done"] == k + 1) and np.all(got["exit_codes"] == 0)
+    finally:
+        sess.close()
+
+
+def test_checkpoint_resume_is_bit_identical():
+    """state() after step 7, restore() into a fresh session, run the rest: identical bits to an uninterrupted run."""
+    p = configs.build(3, batch=6, horizon=16)
+    idx = np.arange(6)
+    full = _gpu_batch(p, idx)
+    s1 = _session(p, 6)
+    s2 = _session(p, 6)
+    try:
+        for s in (s1, s2):
+            s.load_problem(p["models"], p["x0"], p["X_targ"], p["U_targ"], p["Q"], p["R"], p["Qf"], p["plant_op0"],
+                           p["plant_ops"])
+        s1.run(0, 7)
+        s2.restore(s1.state())
+        s2.run(7, p["n_steps"])
+        r2 = s2.results()
+    finally:
+        s1.close()
+        s2.close()
+    assert np.array_equal(np.swapaxes(r2["xs"], 1, 2), full["xs"])
+    assert np.array_equal(np.swapaxes(r2["us"], 1, 2), full["us"])
+    assert np.all(r2["steps_done"] == p["n_steps"])
+
+
+def test_closed_loop_full_horizon_config3_sample():
+    """BASELINE config 3 at its own T = 40 on a 4-member sample of the 65,536 ensemble, free running."""
+    p = configs.build(3, batch=64)
+    idx = np.array([0, 17, 42, 63])
+    res = _gpu_batch(p, idx)
+    xs, us, codes, solves = _oracle_batch(p, idx)
+    assert np.array_equal(res["qp_solves"], solves)
+    assert rel(res["us"][:, :, 0], us[:, :, 0]) <= 1e-10 and rel(res["xs"][:, :, 1], xs[:, :, 1]) <= 1e-10
+    eu, ex = _envelope(p, idx, xs, us)
+    assert np.all(np.abs(res["us"] - us).max(axis=(0, 1)) <= 1e-9 + 100 * eu)
+    assert np.all(np.abs(res["xs"] - xs).max(axis=(0, 1))[1:] <= 1e-9 + 100 * ex[1:])
+
+
+def test_closed_loop_no_warm_start_and_max_iter():
+    p = configs.build(1, batch=1)
+    res = _gpu_batch(p, np.arange(1), warm_start=False, max_iter=3)
+    xs, us, codes, solves = _oracle_batch(p, np.arange(1), warm_start=False, max_iter=3)
+    assert np.array_equal(res["qp_solves"], solves) and solves.max() == 3
+    assert rel(res["us"][:, :, :3], us[:, :, :3]) <= 1e-9 and rel(res["xs"][:, :, :4], xs[:, :, :4]) <= 1e-9
+    assert rel(res["us"], us) <= 1e-5 and rel(res["xs"], xs) <= 1e-5
+
+
+def test_closed_loop_lqr_mode_vs_oracle():
+    """The whole loop with quad_program = the reference's lqr.py arithmetic."""
+    p = configs.build(1, batch=1)
+    res = _gpu_batch(p, np.arange(1), qp_flags=_lib.QP_REF_LQR)
+    xs, us, codes, solves = _oracle_batch(p, np.arange(1), qp_mode="lqr")
+    assert np.array_equal(res["qp_solves"], solves)
+    assert rel(res["us"][:, :, :3], us[:, :, :3]) <= 1e-9 and rel(res["xs"][:, :, :4], xs[:, :, :4]) <= 1e-9
+    assert rel(res["us"], us) <= 1e-5 and rel(res["xs"], xs) <= 1e-5
+
+
+def test_mpc_dropin_fused_equals_host_plant_and_oracle():
+    """mpc() with this package's QExperiment (fused, one launch) == mpc() with a foreign experiment object
+    (one launch per step, plant on the host) == oracle; return shapes and clock mutation as mpc.py:294-304."""
+    p = configs.build(3, batch=1, horizon=12, n_steps=8)
+    n, m = p["dim_x"], p["dim_u"]
+    model = m4q.DMDc(n, n, p["models"].shape[2] - n, p["models"][0])
+
+    def run(exp, **kw):
+        clock = m4q.StepClock(p["dt"], p["horizon"], p["n_steps"])
+        out = m4q.mpc(p["x0"][0], m, p["order"], p["X_targ"], p["U_targ"], clock, exp, model, p["Q"], p["R"], p["Qf"],
+                      sat=p["sat"], du=p["du"], progress_bar=False, **kw)
+        return out, clock
+    (d1, _, c1), clk1 = run(m4q.QExperiment(p["plant_op0"][0], list(p["plant_ops"][0])))
+    (d2, _, c2), clk2 = run(orc.OracleQExperiment(p["plant_op0"][0], list(p["plant_ops"][0])))
+    oclk = orc.OracleClock(p["dt"], p["horizon"], p["n_steps"])
+    (xo, uo), _, co = orc.mpc(p["x0"][0], m, p["order"], p["X_targ"], p["U_targ"], oclk,
+                              orc.OracleQExperiment(p["plant_op0"][0], list(p["plant_ops"][0])),
+                              orc.OracleDMDc(n, n, p["models"].shape[2] - n, p["models"][0]), p["Q"], p["R"], p["Qf"],
+                              sat=p["sat"], du=p["du"])
+    assert c1 == c2 == co == 0
+    assert d1[0].shape == (n, 9) and d1[1].shape == (m, 8)
+    assert len(clk1.ts_sim) == len(clk2.ts_sim) == len(oclk.ts_sim) == 8
+    assert rel(d1[0], xo) <= 1e-8 and rel(d1[1], uo) <= 1e-8
+    assert rel(d2[0], xo) <= 1e-8 and rel(d2[1], uo) <= 1e-8
+
+
+def test_mpc_exit_condition_and_exit_code_1():
+    p = configs.build(1, batch=1)
+    model = m4q.DMDc(4, 4, 4, p["models"][0])
+    clock = m4q.StepClock(p["dt"], p["horizon"], p["n_steps"])
+    exp = m4q.QExperiment(p["plant_op0"][0], list(p["plant_ops"][0]))
+    (xs, us), _, code = m4q.mpc(p["x0"][0], 1, 1, p["X_targ"], p["U_targ"], clock, exp, model, p["Q"], p["R"], p["Qf"],
+                                sat=p["sat"], du=p["du"], progress_bar=False,
+                                exit_condition=lambda xn, x, u: xn[3].real > 0.5)
+    oclk = orc.OracleClock(p["dt"], p["horizon"], p["n_steps"])
+    (xo, uo), _, co = orc.mpc(p["x0"][0], 1, 1, p["X_targ"], p["U_targ"], oclk,
+                              orc.OracleQExperiment(p["plant_op0"][0], list(p["plant_ops"][0])),
+                              orc.OracleDMDc(4, 4, 4, p["models"][0]), p["Q"], p["R"], p["Qf"], sat=p["sat"], du=p["du"],
+                              exit_condition=lambda xn, x, u: xn[3].real > 0.5)
+    assert code == co == 1
+    assert xs.shape == xo.shape and us.shape == uo.shape and len(clock.ts_sim) == len(oclk.ts_sim)
+    assert rel(xs, xo) <= 1e-8 and rel(us, uo) <= 1e-8
+
+
+def test_exit_code_3_on_nonfinite_model():
+    p = configs.build(2, batch=5)
+    models = np.repeat(p["models"], 5, axis=0)
+    models[3, 0, 0] = np.nan
+    clock = m4q.StepClock(p["dt"], p["horizon"], p["n_steps"])
+    res = m4q.mpc_batch(p["x0"], models, 1, 1, p["X_targ"], p["U_targ"], clock, p["plant_op0"], p["plant_ops"], p["Q"],
+                        p["R"], p["Qf"], p["sat"], p["du"])
+    assert res["exit_codes"].tolist() == [0, 0, 0, 3, 0]
+    assert res["steps_done"].tolist() == [20, 20, 20, 0, 20]
+    assert res["qp_solves"][3, 0] == 1 and res["qp_solves"][3, 1:].sum() == 0
+
+
+# ---------------------------------------------------------------- size-independent properties at scale
+@pytest.mark.parametrize("cfg,batch", [(2, 8192), (3, 4096)])
+def test_properties_at_scale(cfg, batch):
+    """Full BASELINE sizes are beyond the oracle's reach; check what must hold for every member:
+    unit trace and Hermiticity of rho_t (the plant is unitary), |u| <= sat, the du band on the first control
+    of every step, completion, and bit-identical results for identical members placed in different wavefronts."""
+    p = configs.build(cfg, batch=batch)
+    if cfg == 3:
+        p["models"][batch - 1] = p["models"][0]
+        p["x0"][batch - 1] = p["x0"][0]
+    else:
+        p["x0"][batch - 1] = p["x0"][0]
+        p["x0"][batch // 2 + 1] = p["x0"][0]
+    res = _gpu_batch(p, np.arange(batch))
+    d = p["d"]
+    assert np.all(res["exit_codes"] == 0) and np.all(res["steps_done"] == p["n_steps"])
+    rho = np.swapaxes(res["xs"], 1, 2).reshape(batch, p["n_steps"] + 1, d, d)
+    assert np.abs(rho.trace(axis1=2, axis2=3) - 1).max() < 1e-10
+    assert np.abs(rho - np.swapaxes(rho.conj(), 2, 3)).max() < 1e-10
+    assert np.abs(res["us"]).max() <= p["sat"] * (1 + 1e-15)
+    dus = np.abs(np.diff(res["us"], axis=2))[:, :, 1:]          # steps >= 2 are banded around us[step-1]
+    assert dus.max() <= p["du"] * (1 + 1e-12)
+    assert np.array_equal(res["xs"][0], res["xs"][batch - 1]) and np.array_equal(res["us"][0], res["us"][batch - 1])
+    if cfg == 2:
+        assert np.array_equal(res["us"][0], res["us"][batch // 2 + 1])
+    assert res["qp_solves"][:, 2:].min() == 1 and res["qp_solves"][:, 2:].max() == 1
