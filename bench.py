@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py - MPC horizon-steps/s of the fused closed-loop kernel on BASELINE config 3
+(3-level transmon, n=9, m=2, T=40, n_steps=20, 65,536-member model ensemble per GPU).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 3] [--batch B]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One "step" = one complete receding-horizon run (all n_steps MPC steps, every SQP iteration, plant
+propagation) of the rank's whole ensemble, inputs resident in HBM.  Unit of work = one MPC
+horizon-step: value = sum over ranks, instances and MPC steps of qp_solves * T,
+divided by the max-over-ranks time of the K timed steps.  The ensemble shards with no data-path
+collective; one gather of the results closes each step when N > 1 (weak scaling: per-GPU batch fixed).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic work per horizon-step (SURVEY.md 8d / BASELINE.md 4), order 1
+ALG_FLOP = {4: 3.5e3, 9: 27e3, 16: 126e3}
+PEAK_F64_TFLOPS = 78.6      # MI355X fp64 vector == fp64 matrix dense rate (AMD spec; 256 CU x 4 SIMD x 16 FMA lanes x 2.4 GHz)
+PEAK_HBM_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def alg_bytes_per_hstep(n, m, P, T):
+    """model + X_guess in + U_guess in + X_opt, U_opt out, per QP solve, divided by T."""
+    return (16 * n * n * (1 + P) + 16 * n * (T + 1) + 8 * m * T + 16 * n * (T + 1) + 8 * m * T) / T
+
+
+def cpu_baseline(p, seconds_budget=20.0):
+    """The NumPy oracle (a port of the reference arithmetic) on one host core, on the first members
+    of the same ensemble until ~seconds_budget is spent."""
+    from oracle import m4q_oracle as orc
+    import numpy as np
+    t0 = time.perf_counter()
+    units = 0
+    done = 0
+    while done < p["x0"].shape[0] and (time.perf_counter() - t0 < seconds_budget or done < 2):
+        mdl = p["models"][done:done + 1] if p["models"].shape[0] > 1 else p["models"]
+        _, _, _, solves = orc.mpc_batch(p["x0"][done:done + 1], mdl, p["dim_u"], p["order"], p["X_targ"], p["U_targ"], p["dt"],
+                                        p["horizon"], p["n_steps"], p["plant_op0"], list(p["plant_ops"][0]), p["Q"], p["R"],
+                                        p["Qf"], p["sat"], p["du"])
+        units += int(solves.sum()) * p["horizon"]
+        done += 1
+    dt = time.perf_counter() - t0
+    return {"value": units / dt, "unit": "MPC horizon-steps/s", "cores": 1, "kind": "port",
+            "sample": "first %d of %d ensemble members, full closed loop (n_steps=%d, T=%d), NumPy oracle, %.1f s"
+                      % (done, p["x0"].shape[0], p["n_steps"], p["horizon"], dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=None, help="ensemble members per GPU (default: the config's own size)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import numpy as np
+    from mpc4quantum_amd import _lib, configs
+    from mpc4quantum_amd.session import EnsembleSession
+
+    p = configs.build(args.config, batch=args.batch)
+    # each rank takes its own slice of a world-sized ensemble: different seeds per rank would change the
+    # workload; the config's generator is deterministic, so ranks differ by an index offset into a larger draw
+    if world > 1:
+        big = configs.build(args.config, batch=p["batch"] * world)
+        sl = slice(rank * p["batch"], (rank + 1) * p["batch"])
+        p["x0"] = np.ascontiguousarray(big["x0"][sl])
+        if big["models"].shape[0] > 1:
+            p["models"] = np.ascontiguousarray(big["models"][sl])
+    B, n, m, T, ns = p["batch"], p["dim_x"], p["dim_u"], p["horizon"], p["n_steps"]
+    P = p["models"].shape[2] // n - 1
+
+    sess = EnsembleSession(B, n, m, p["order"], T, ns, p["dt"], p["sat"], p["du"], model_per_instance=p["models"].shape[0] > 1,
+                           target_cols=ns + T + 1, device=local_rank if world > 1 else -1)
+    gather_bufs = None
+    if world > 1:
+        # results live in torch-owned HBM so RCCL can gather them without a copy
+        us_t = torch.empty(B * ns * m, dtype=torch.float64, device="cuda")
+        xs_t = torch.empty(B * (ns + 1) * n * 2, dtype=torch.float64, device="cuda")
+        sess.bind_output(_lib.F_US, us_t.data_ptr(), us_t.numel() * 8)
+        sess.bind_output(_lib.F_XS, xs_t.data_ptr(), xs_t.numel() * 8)
+        us_all = torch.empty(world * us_t.numel(), dtype=torch.float64, device="cuda") if rank == 0 else None
+        gather_bufs = (us_t, us_all)
+    sess.load_problem(p["models"], p["x0"], p["X_targ"], p["U_targ"], p["Q"], p["R"], p["Qf"], p["plant_op0"], p["plant_ops"])
+
+    def one_step():
+        sess.run(0, ns)
+        if world > 1:
+            sess.sync()
+            us_t, us_all = gather_bufs
+            xs_final = xs_t.view(B, ns + 1, n * 2)[:, -1, :].contiguous()
+            outs = [torch.empty_like(xs_final) for _ in range(world)] if rank == 0 else None
+            dist.gather(xs_final, outs, dst=0)                     # the one RCCL collective of the job
+            chunks = list(us_all.chunk(world)) if rank == 0 else None
+            dist.gather(us_t, chunks, dst=0)
+
+    def fence():
+        sess.sync()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    sess.kernel_ms()                                               # drop warm-up launches from the event log
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kern_ms, launches = sess.kernel_ms()
+
+    res = sess.results()
+    units_per_step = int(res["qp_solves"].astype(np.int64).sum()) * T
+    ok = int((res["exit_codes"] == 0).sum())
+    info = sess.info()
+    if world > 1:
+        t = torch.tensor([elapsed, float(units_per_step), float(ok)], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+        units_total = float(t[1])
+        ok_total = int(t[2])
+    else:
+        units_total = float(units_per_step)
+        ok_total = ok
+
+    if rank == 0:
+        value = units_total * args.steps / elapsed
+        avg_launch_s = kern_ms / max(launches, 1) / 1e3
+        flops = ALG_FLOP[n] * units_per_step
+        abytes = alg_bytes_per_hstep(n, m, P, T) * units_per_step
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get("config%d_B%d" % (args.config, B))
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "MPC horizon-steps/sec across batch (3-level transmon, T=40)" if args.config == 3
+                      else "MPC horizon-steps/sec across batch (config %d)" % args.config,
+            "value": value, "unit": "MPC horizon-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE config %d: d=%d (n=%d, m=%d), order %d, T=%d, n_steps=%d, %d ensemble members per GPU, "
+                                   "per-instance models, full closed loop per step" % (args.config, p["d"], n, m, p["order"], T, ns, B),
+                       "batch_per_gpu": B, "horizon": T, "n_steps": ns, "qp_solves_per_step": units_per_step // T,
+                       "instances_ok": ok_total, "parallelism": "ensemble-sharded x%d, one gather" % world,
+                       "grid": info["grid"], "lds_bytes": info["lds_bytes"], "hbm_resident_bytes": info["hbm_bytes"]},
+            "roofline": {"bound": "mfma", "achieved": flops / avg_launch_s / 1e12, "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flops / avg_launch_s / 1e12 / PEAK_F64_TFLOPS, "traffic": traffic,
+                         "kernel": "mpc_kernel<PLANT_HAMILTONIAN>", "launches": launches, "avg_launch_ms": 1e3 * avg_launch_s,
+                         "note": "fp64 compute roof: v_fma_f64 (VALU, used here with DPP row broadcasts) and v_mfma_f64 share the "
+                                 "78.6 TFLOP/s dense rate on MI355X; algorithmic flops = 27 kflop/horizon-step (SURVEY 8d)",
+                         "hbm": {"achieved": abytes / avg_launch_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "frac": abytes / avg_launch_s / 1e9 / PEAK_HBM_GBS}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(p)
+        print(json.dumps(out))
+    sess.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

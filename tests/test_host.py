@@ -1,0 +1,162 @@
+"""CPU tests (-m "not gpu"): host-side logic of the product against the oracle and the reference-made
+goldens, the C ABI surface, and loud failure without a device."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import mpc4quantum_amd as m4q
+from mpc4quantum_amd import _lib
+from mpc4quantum_amd.distributed import shard_bounds
+from oracle import m4q_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("order", [1, 2, 3])
+@pytest.mark.parametrize("m", [1, 2, 3])
+def test_library_tables_vs_reference_golden(golden, order, m):
+    g = golden("library_tables")
+    key = "o%d_m%d" % (order, m)
+    assert np.array_equal(np.vstack(m4q.create_power_list(order, m)), g[key + "_powers"])
+    assert m4q.size_of_library(order, m) == int(g[key + "_size"])
+    u = g[key + "_u"]
+    assert np.allclose(np.vstack([f(u) for f in m4q.create_library(order, m)]), g[key + "_lib"], rtol=0, atol=1e-12)
+    fns, coefs = m4q.diff_library(order, m)
+    assert np.array_equal(np.stack([c.reshape(-1) for c in coefs]), g[key + "_dcoef"])
+    assert np.allclose(np.stack([np.vstack([f(u) for f in fl]) for fl in fns]), g[key + "_dlib"], rtol=0, atol=1e-12)
+    assert [tuple(p) for p in m4q.multinomial_powers(order, m + 1)] == \
+           [tuple(int(v) for v in p) for p in orc.multinomial_powers(order, m + 1)]
+
+
+@pytest.mark.parametrize("order,m", [(1, 1), (2, 1), (1, 2), (2, 2), (1, 3)])
+def test_device_power_table_matches_host(order, m):
+    """The compile-time table inside the kernels (csrc/m4q_mpc.h PowTab) == linearize.create_power_list."""
+    P = m4q.size_of_library(order, m)
+    out = np.zeros(P * m, dtype=np.int32)
+    got = _lib.lib().m4q_power_list(order, m, out.ctypes.data_as(_lib._ip))
+    assert got == P == _lib.lib().m4q_library_size(order, m) + 1
+    assert np.array_equal(out.reshape(P, m), np.vstack(m4q.create_power_list(order, m)))
+
+
+def test_krtimes(golden):
+    g = golden("library_tables")
+    assert np.allclose(m4q.krtimes(g["kr_a"], g["kr_b"]), g["kr_out"], rtol=0, atol=1e-13)
+    with pytest.raises(ValueError):
+        m4q.krtimes(np.ones((2, 3)), np.ones((2, 4)))
+
+
+@pytest.mark.parametrize("name,order", [("qubit", 1), ("qubit", 2), ("transmon", 1), ("transmon", 2), ("coupled", 1)])
+def test_discretize_vs_reference_golden(golden, name, order):
+    g = golden("discretize")
+    out = m4q.discretize_homogeneous(list(g[name + "_A_cts"]), float(g[name + "_dt"]), order)
+    assert np.abs(out - g["%s_o%d" % (name, order)]).max() <= 1e-12
+
+
+def test_discretize_known_answer_and_batched():
+    """reference tests/test_mpc4quantum.py:147-188: order 1, dt 1 -> [I + A | N_1 | N_2]."""
+    sx = np.array([[0, 1], [1, 0]], dtype=complex)
+    sy = np.array([[0, -1j], [1j, 0]], dtype=complex)
+    basis = [np.outer(np.eye(2)[i], np.eye(2)[j]) for i in range(2) for j in range(2)]
+    l1 = [m4q.vectorize_me(op, basis) for op in (0 * sx, sx)]
+    l2 = [m4q.vectorize_me(op, basis) for op in (0 * sy, sy)]
+    z = np.zeros((4, 4))
+    ops = [np.block([[l1[0], z], [z, l2[0]]]), np.block([[l1[1], z], [z, z]]), np.block([[z, z], [z, l2[1]]])]
+    out = m4q.discretize_homogeneous(ops, 1, 1)
+    assert np.isclose(out, np.hstack([ops[0] + np.identity(8), ops[1], ops[2]])).all()
+    assert np.abs(m4q.vectorize_me(sx + 0.3 * sy, basis) - m4q.liouvillian(sx + 0.3 * sy)).max() < 1e-14
+    stacked = m4q.discretize_homogeneous([np.stack([o, 2 * o]) for o in ops], 0.5, 2)
+    assert np.abs(stacked[1] - orc.discretize_homogeneous([2 * o for o in ops], 0.5, 2)).max() < 1e-12
+
+
+def test_clock_and_small_helpers():
+    c, o = m4q.StepClock(0.25, 16, 20), orc.OracleClock(0.25, 16, 20)
+    for k in (0, 3, 19):
+        assert np.array_equal(c.ts_step(k), o.ts_step(k)) and np.array_equal(c.ts_horizon(k), o.ts_horizon(k))
+    assert np.array_equal(c.ts, o.ts)
+    c.set_endsim(7)
+    assert len(c.ts_sim) == 7
+    assert m4q.val_to_str(1e-2) == "1d0em02" and m4q.val_to_str(0.25) == "2d5em01"
+    assert c.to_string() == "mf_1d0e00_dt_2d5em01_h_1d6e01_n_2d0e01"
+    a = np.arange(12).reshape(3, 4)
+    assert np.array_equal(m4q.shift_guess(a), orc.shift_guess(a))
+    assert np.array_equal(m4q.shift_guess(a)[:, -1], a[:, -1]) and np.array_equal(m4q.shift_guess(a)[:, 0], a[:, 1])
+
+
+def test_line_search_host_form_vs_oracle():
+    rng = np.random.default_rng(4)
+    n, m, T = 4, 1, 5
+    Q = np.diag([1.0, 0, 0, 1.0])
+    Q_ls, R_ls = [Q] * T + [2 * Q], [0.3 * np.eye(m)] * T
+    Xt, Xg, Xo = (rng.standard_normal((n, T + 1)) + 1j * rng.standard_normal((n, T + 1)) for _ in range(3))
+    Ut, Ug, Uo = (rng.standard_normal((m, T)) for _ in range(3))
+    a1, s1, _, _ = m4q.iqp_line_search(Q_ls, R_ls, Xt, Ut, Xg, Ug, Xo, Uo)
+    a2, s2 = orc.iqp_line_search(Q_ls, R_ls, Xt, Ut, Xg, Ug, Xo, Uo)
+    assert abs(a1 - a2) < 1e-12 and abs(s1 - s2) < 1e-12
+
+
+def test_dmdc_container():
+    A = np.arange(24).reshape(4, 6) + 1j
+    d = m4q.DMDc(4, 4, 2, A)
+    ax, au = d.get_discrete()
+    assert ax.shape == (4, 4) and au.shape == (4, 2)
+    x, u = np.ones(4), np.ones(2)
+    assert np.allclose(d.predict(x, u), (ax @ x + au @ u).reshape(4, 1))
+
+
+def test_wrapmodel_dimension_check_needs_no_gpu():
+    with pytest.raises(ValueError):
+        m4q.WrapModel(np.eye(4), np.zeros((4, 12)), 1, 1)
+    wm = m4q.WrapModel(np.eye(4), np.zeros((4, 8)), 1, 2)
+    assert wm.lift_u(np.array([[2.0]])).reshape(-1).tolist() == [2.0, 4.0]
+
+
+def test_shard_bounds_cover_everything():
+    for B in (1, 7, 64, 65536):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(B, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+# ---------------------------------------------------------------- C ABI surface
+def test_abi_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "m4q.h")).read()
+    declared = set(re.findall(r"M4Q_API[^;(]*?\b(m4q_[a-z_0-9]+)\s*\(", header))
+    assert len(declared) >= 24
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(handle, name), name
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    assert _lib.lib().m4q_version().startswith(b"m4q-hip")
+
+
+def test_problem_struct_layout_matches_header():
+    header = open(os.path.join(ROOT, "include", "m4q.h")).read()
+    body = header[header.index("typedef struct m4q_problem {"):header.index("} m4q_problem;")]
+    fields = re.findall(r"^\s*(int32_t|double)\s+(\w+);", body, re.M)
+    assert [f for _, f in fields] == [f for f, _ in _lib.Problem._fields_]
+    assert ctypes.sizeof(_lib.Problem) == 14 * 4 + 4 * 8
+
+
+def test_supported_shapes():
+    assert _lib.supported(4, 1, 1) and _lib.supported(9, 2, 1) and _lib.supported(9, 2, 2) and _lib.supported(16, 3, 1)
+    assert not _lib.supported(25, 1, 1)
+
+
+def test_fails_loudly_without_a_gpu():
+    """The product has no CPU path: on a box with no device every compute entry point raises."""
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is present")
+    wm = m4q.WrapModel(np.eye(4), np.zeros((4, 4)), 1, 1)
+    with pytest.raises(_lib.M4qError):
+        wm.get_model_along_traj(np.zeros((4, 3), dtype=complex), np.zeros((1, 3)), np.arange(3))
+    with pytest.raises(_lib.M4qError):
+        m4q.EnsembleSession(4, 4, 1, 1, 5, 3, 1.0, 0.5)
+    with pytest.raises(_lib.M4qError):
+        m4q.plant_step_batch(np.zeros((1, 4)), np.zeros((1, 1)), np.eye(2), np.eye(2)[None], 0.1)
+    with pytest.raises(TypeError):
+        m4q.EnsembleSession(4, 4, 1, 1, 5, 3, 1.0, None)
