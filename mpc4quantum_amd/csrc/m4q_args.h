@@ -20,8 +20,10 @@ struct MpcArgs {
   const cplx* op0; long op0_stride;         // plant operators
   const cplx* ops; long ops_stride;
   cplx* xs; double* us; int* codes; int* steps_done; int* qp_solves;
-  cplx* Xg; double* Ug;                     // per-instance SQP guess  [B][T+1][n], [B][T][m]
-  cplx* ws_Xo; double* ws_Uo; cplx* ws_gains;   // per resident row: [grid*4][T+1][n], [..][T][m], [..][T][n+1][m]
+  cplx* Xg; double* Ug;                     // per-instance SQP guess  [B][T+1][n], [B][T][m] (resumable state)
+  // per resident row (grid*4 of them): working guess, QP solution, gains
+  cplx* ws_Xg; double* ws_Ug; cplx* ws_Xo; double* ws_Uo; cplx* ws_gains;
+  int* queue;                               // next instance to hand out; zeroed before every launch
 };
 
 struct LinArgs {

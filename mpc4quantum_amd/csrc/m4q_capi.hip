@@ -111,7 +111,7 @@ struct m4q_session {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int grid = 1;
   DevBuf f[M4Q_F_COUNT];
-  DevBuf Cq, Cqf, Cr, wsXo, wsUo, wsG;
+  DevBuf Cq, Cqf, Cr, wsXg, wsUg, wsXo, wsUo, wsG, queue;
   size_t fbytes[M4Q_F_COUNT]{};
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
   double ms_total = 0.0;
@@ -158,6 +158,15 @@ int m4q_session_create(const m4q_problem* p, int32_t B, int32_t device, m4q_sess
   if (p->horizon < 1 || p->n_steps < 1 || p->target_cols < p->horizon + 1 + (p->n_steps > 1 ? p->n_steps - 2 : 0))
     return fail(M4Q_E_BADARG, "horizon/n_steps/target_cols inconsistent (need target_cols >= n_steps + horizon - 1)");
   if (!(p->sat > 0)) return fail(M4Q_E_BADARG, "sat must be positive (the reference crashes on sat=None, mpc.py Q5)");
+  {
+    // per-instance targets / plant operators are reached through 32-bit byte offsets from one base
+    const double lim = 4294967296.0;
+    const double kk = p->plant_kind == M4Q_PLANT_GENERATOR ? p->dim_x : dim_d(p->dim_x);
+    if (p->target_per_instance && (double)B * p->target_cols * p->dim_x * 16.0 >= lim)
+      return fail(M4Q_E_BADARG, "per-instance targets must stay below 4 GiB in total");
+    if (p->plant_per_instance && (double)B * p->dim_u * kk * kk * 16.0 >= lim)
+      return fail(M4Q_E_BADARG, "per-instance plant operators must stay below 4 GiB in total");
+  }
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev == 0) return fail(M4Q_E_NODEVICE, "no HIP device: %s", hipGetErrorString(e));
@@ -201,6 +210,9 @@ int m4q_session_create(const m4q_problem* p, int32_t B, int32_t device, m4q_sess
   long resident = (long)per_cu * prop.multiProcessorCount;
   s->grid = (int)(nquads < resident ? nquads : resident);
   const size_t rows = (size_t)s->grid * 4;
+  if (!rc) rc = s->wsXg.alloc(rows * (T + 1) * n * C);
+  if (!rc) rc = s->wsUg.alloc(rows * T * m * 8);
+  if (!rc) rc = s->queue.alloc(64);
   if (!rc) rc = s->wsXo.alloc(rows * (T + 1) * n * C);
   if (!rc) rc = s->wsUo.alloc(rows * T * m * 8);
   if (!rc) rc = s->wsG.alloc(rows * T * (n + 1) * m * C);
@@ -323,7 +335,10 @@ int m4q_session_run(m4q_session* s, int32_t step_begin, int32_t step_end) {
   a.xs = (cplx*)s->f[M4Q_F_XS].p; a.us = (double*)s->f[M4Q_F_US].p;
   a.codes = (int*)s->f[M4Q_F_CODES].p; a.steps_done = (int*)s->f[M4Q_F_STEPS_DONE].p; a.qp_solves = (int*)s->f[M4Q_F_QP_SOLVES].p;
   a.Xg = (cplx*)s->f[M4Q_F_X_GUESS].p; a.Ug = (double*)s->f[M4Q_F_U_GUESS].p;
+  a.ws_Xg = (cplx*)s->wsXg.p; a.ws_Ug = (double*)s->wsUg.p;
   a.ws_Xo = (cplx*)s->wsXo.p; a.ws_Uo = (double*)s->wsUo.p; a.ws_gains = (cplx*)s->wsG.p;
+  a.queue = (int*)s->queue.p;
+  HIP_TRY(hipMemsetAsync(s->queue.p, 0, 64, s->stream));
   if (step_begin == 0) {
     HIP_TRY(hipMemsetAsync(s->f[M4Q_F_QP_SOLVES].p, 0, s->fbytes[M4Q_F_QP_SOLVES], s->stream));
     HIP_TRY(hipMemsetAsync(s->f[M4Q_F_CODES].p, 0, s->fbytes[M4Q_F_CODES], s->stream));
@@ -376,7 +391,7 @@ int m4q_session_info(const m4q_session* s, int64_t* hbm_bytes, int32_t* grid, in
   if (!s) return fail(M4Q_E_BADARG, "m4q_session_info: null session");
   int64_t tot = 0;
   for (int i = 0; i < M4Q_F_COUNT; ++i) tot += (int64_t)s->f[i].bytes;
-  tot += (int64_t)(s->wsXo.bytes + s->wsUo.bytes + s->wsG.bytes);
+  tot += (int64_t)(s->wsXg.bytes + s->wsUg.bytes + s->wsXo.bytes + s->wsUo.bytes + s->wsG.bytes);
   if (hbm_bytes) *hbm_bytes = tot;
   if (grid) *grid = s->grid;
   if (lds_bytes) *lds_bytes = (int32_t)s->shape->mpc_lds_bytes();

@@ -63,7 +63,17 @@ struct LaneGeo {
 
 // ---------------------------------------------------------------------------------------------
 // The fused closed loop (replaces mpc.py:161-292).
+//
+// Scheduling: the wavefront is a four-slot machine.  Every DPP row pulls its OWN next instance from a
+// device-wide atomic queue and carries its own (instance, MPC step, SQP iteration); one pass of the main
+// loop performs one QP solve for each row at whatever point of its run that row has reached.  SQP
+// iteration counts at steps 0-1 range from 14 to 100 (config 3): with rows in lockstep a quad runs at
+// the pace of its slowest member and a static split leaves the slowest wave 1.6x the mean.
 // ---------------------------------------------------------------------------------------------
+constexpr int COST_ELEMS = 2 * NX * NX + NU * NU;         // Q, Qf, R staged in LDS once per workgroup
+
+__device__ __forceinline__ int row_bcast_int(int v) { return __shfl(v, 0, 16); }
+
 template <int PLANT>
 __global__ __launch_bounds__(64) M4Q_OCC void mpc_kernel(MpcArgs a) {
   cplx* lds = reinterpret_cast<cplx*>(m4q_lds_raw);
@@ -73,131 +83,156 @@ __global__ __launch_bounds__(64) M4Q_OCC void mpc_kernel(MpcArgs a) {
   const int T = a.T;
   cplx* mdl = lds + g * MODEL_ELEMS;
   cplx* scratch = lds + ROWS * MODEL_ELEMS + g * SCRATCH_ELEMS;
-  // workspace of this resident row: uniform base per workgroup, lane part = row within the wave
-  const unsigned sXo = (unsigned)(T + 1) * NX, sUo = (unsigned)T * NU, sG = (unsigned)T * (NX + 1) * NU;
-  const GView Xo = gview(a.ws_Xo, (long)blockIdx.x * ROWS * sXo, g * sXo);
-  const GView Uo = gview(a.ws_Uo, (long)blockIdx.x * ROWS * sUo, g * sUo);
-  const GView gains = gview(a.ws_gains, (long)blockIdx.x * ROWS * sG, g * sG);
+  cplx* ldsQ = lds + ROWS * (MODEL_ELEMS + SCRATCH_ELEMS);
+  for (int e = threadIdx.x; e < COST_ELEMS; e += 64)
+    ldsQ[e] = e < NX * NX ? a.Q[e] : (e < 2 * NX * NX ? a.Qf[e - NX * NX] : a.R[e - 2 * NX * NX]);
   CostRef cost;
-  cost.Q = a.Q; cost.Qf = a.Qf; cost.q_stride = 0; cost.R = a.R; cost.r_stride = 0;
-  const int nquads = (a.B + ROWS - 1) / ROWS;
-  const unsigned sXs = (unsigned)(a.n_steps + 1) * NX, sUs = (unsigned)a.n_steps * NU;
+  cost.Q = ldsQ; cost.Qf = ldsQ + NX * NX; cost.q_stride = 0; cost.R = ldsQ + 2 * NX * NX; cost.r_stride = 0;
+  // workspace of this resident row: wave-uniform base per workgroup, lane part = row within the wave
+  const unsigned sX = (unsigned)(T + 1) * NX, sU = (unsigned)T * NU, sG = (unsigned)T * (NX + 1) * NU;
+  const GView Xg = gview(a.ws_Xg, (long)blockIdx.x * ROWS * sX, g * sX);
+  const GView Ug = gview(a.ws_Ug, (long)blockIdx.x * ROWS * sU, g * sU);
+  const GView Xo = gview(a.ws_Xo, (long)blockIdx.x * ROWS * sX, g * sX);
+  const GView Uo = gview(a.ws_Uo, (long)blockIdx.x * ROWS * sU, g * sU);
+  const GView gains = gview(a.ws_gains, (long)blockIdx.x * ROWS * sG, g * sG);
+  FusedProv<NX, NU, ORDER> prov;
+  prov.mdl = mdl; prov.Xg = Xg; prov.Ug = Ug; prov.j = j;
+  const long sXs = (long)(a.n_steps + 1) * NX, sUs = (long)a.n_steps * NU;
+  const bool band = (a.flags & QP_DU_BAND) != 0;
 
-  for (int quad = blockIdx.x; quad < nquads; quad += gridDim.x) {
-    const long q0 = (long)quad * ROWS;                  // first instance of the quad (uniform)
-    const bool valid = q0 + g < a.B;
-    const unsigned gl = valid ? g : (unsigned)(a.B - 1 - q0);   // row clamped into the ensemble
-    const long b = q0 + gl;
-    __syncthreads();                                   // previous quad is done with the LDS model
-    stage_model(mdl, gview(a.models, q0 * a.model_stride, gl * (unsigned)a.model_stride), jj);
+  // per-row state (uniform inside a row)
+  long b = 0;
+  bool active = false, need_new = true;
+  int step = 0, iter = 0, code = 0, done_steps = 0;
+  cplx x_cur = czero();
+  double uprev[NU];
+#pragma unroll
+  for (int k = 0; k < NU; ++k) uprev[k] = 0.0;
+  GView xt = gview(a.x_targ, 0, 0), ut = gview(a.u_targ, 0, 0), op0 = gview(a.op0, 0, 0), ops = gview(a.ops, 0, 0);
+  __syncthreads();
+
+  while (true) {
+    // ---- rows without work draw the next instance ----
+    if (__any(need_new)) {
+      int nb = 0;
+      if (need_new && jj == 0) nb = atomicAdd(a.queue, 1);
+      nb = row_bcast_int(nb);
+      const bool fresh = need_new && nb < a.B;
+      if (need_new) { active = fresh; need_new = false; }
+      if (fresh) b = nb;
+      __syncthreads();
+      if (fresh) {
+        stage_model(mdl, gview(a.models + b * a.model_stride, 0, 0), jj);
+        xt = gview(a.x_targ, 0, (unsigned)(b * a.xt_stride));
+        ut = gview(a.u_targ, 0, (unsigned)(b * a.ut_stride));
+        op0 = gview(a.op0, 0, (unsigned)(b * a.op0_stride));
+        ops = gview(a.ops, 0, (unsigned)(b * a.ops_stride));
+        step = a.step_begin;
+        iter = 0;
+        if (a.step_begin == 0) {
+          // X_guess = tile(x0), U_guess = 0 (mpc.py:141-142); xs[0] = x0 (:160)
+          const cplx x0 = a.x0[b * NX + j];
+          x_cur = x0;
+          if (lane_ok) {
+            for (int t = 0; t <= T; ++t) Xg.st<cplx>(t * NX + j, x0);
+            a.xs[b * sXs + j] = x0;
+          }
+          for (int e = jj; e < T * NU; e += 16) Ug.st<double>(e, 0.0);
+          code = 0;
+          done_steps = 0;
+        } else {
+          // resume: the SQP guess, state and exit code of a previous launch (fields X_GUESS/U_GUESS/XS/US/CODES)
+          if (lane_ok) {
+            for (int t = 0; t <= T; ++t) Xg.st<cplx>(t * NX + j, a.Xg[b * sX + t * NX + j]);
+          }
+          for (int e = jj; e < T * NU; e += 16) Ug.st<double>(e, a.Ug[b * sU + e]);
+          x_cur = a.xs[b * sXs + (long)a.step_begin * NX + j];
+          code = a.codes[b];
+          done_steps = a.steps_done[b];
+#pragma unroll
+          for (int k = 0; k < NU; ++k) uprev[k] = a.us[b * sUs + (long)(a.step_begin - 1) * NU + k];
+          if (code != 0) step = a.step_end;       // finished earlier (exit code set by the host or the device)
+        }
+      }
+      __syncthreads();
+    }
+    if (!__any(active)) break;
+    const bool running = active && step < a.step_end;
+
+    // ---- one QP solve per row ----
+    // target window: X_ref = X_targ[:, :T+1] for steps 0 and 1, then X_targ[:, step-1:...] (mpc.py:145,276)
+    const int w = step <= 1 ? 0 : step - 1;
+    Window win;
+    win.xbm = xt.lane<cplx>((unsigned)w * NX);
+    win.ubm = ut.lane<double>((unsigned)w * NU);
+    double lo0[NU], hi0[NU];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+      // u_prev = us[step-1] if step > 1 else U_ref[:, 0] (mpc.py:185)
+      const double up = step > 1 ? uprev[k] : win.ubm.ld<double>(k);
+      lo0[k] = band ? up - a.du : -a.sat;
+      hi0[k] = band ? up + a.du : a.sat;
+    }
+    const bool use_ls = !(a.warm_start && step > 1);        // mpc.py:208-213
+    const bool st = running && lane_ok;
+    riccati_backward<NX, NU>(prov, T, win, cost, a.flags, gains, j, st);
     __syncthreads();
-
-    const GView Xg = gview(a.Xg, q0 * sXo, gl * sXo);
-    const GView Ug = gview(a.Ug, q0 * sUo, gl * sUo);
-    const GView xs = gview(a.xs, q0 * sXs, gl * sXs);
-    const GView us = gview(a.us, q0 * sUs, gl * sUs);
-    const GView xt = gview(a.x_targ, q0 * a.xt_stride, gl * (unsigned)a.xt_stride);
-    const GView ut = gview(a.u_targ, q0 * a.ut_stride, gl * (unsigned)a.ut_stride);
-    const GView op0 = gview(a.op0, q0 * a.op0_stride, gl * (unsigned)a.op0_stride);
-    const GView ops = gview(a.ops, q0 * a.ops_stride, gl * (unsigned)a.ops_stride);
-    FusedProv<NX, NU, ORDER> prov;
-    prov.mdl = mdl; prov.Xg = Xg; prov.Ug = Ug; prov.j = j;
-
-    int code;
-    int done_steps;
-    if (a.step_begin == 0) {
-      // X_guess = tile(x0), U_guess = 0 (mpc.py:141-142); xs[0] = x0 (:160)
-      const cplx x0 = a.x0[b * NX + j];
-      if (valid && lane_ok) {
-        for (int t = 0; t <= T; ++t) Xg.st<cplx>(t * NX + j, x0);
-        xs.st<cplx>(j, x0);
-      }
-      if (valid) {
-        for (int e = jj; e < T * NU; e += 16) Ug.st<double>(e, 0.0);
-      }
-      code = 0;
-      done_steps = 0;
-    } else {
-      code = a.codes[b];
-      done_steps = a.steps_done[b];
+    const double chk = rollout_forward<NX, NU, false>(prov, T, x_cur, win, cost, a.flags, gains, a.sat, lo0, hi0, Xo, Uo, j, st);
+    __syncthreads();
+    const bool fail = !finite_d(chk);                      // mpc.py:200-203
+    if (running) ++iter;
+    double alpha = 1.0;
+    bool fin = true;
+    if (__any(running && use_ls)) {
+      ZView<NX, NU> z;
+      z.T = T; z.Xg = Xg; z.Xo = Xo; z.Xt = win.xbm; z.Ug = Ug; z.Uo = Uo; z.Ut = win.ubm;
+      double al, stepn;
+      line_search<NX, NU>(z, a.Cq, a.Cqf, a.Cr, jj, al, stepn);
+      if (use_ls) { alpha = al; fin = stepn < a.ls_tol; }   // mpc.py:224
     }
     __syncthreads();
-    cplx x_cur = xs.ld<cplx>(a.step_begin * NX + j);
+    const bool upd = running && !fail;
+    // X_guess += alpha (X_opt - X_guess) (mpc.py:228-229)
+    if (upd && lane_ok) {
+      for (int t = 0; t <= T; ++t) {
+        const cplx xg = Xg.ld<cplx>(t * NX + j), xo = Xo.ld<cplx>(t * NX + j);
+        Xg.st<cplx>(t * NX + j, mk(xg.re + alpha * (xo.re - xg.re), xg.im + alpha * (xo.im - xg.im)));
+      }
+    }
+    if (upd) {
+      for (int e = jj; e < T * NU; e += 16) {
+        const double ug = Ug.ld<double>(e);
+        Ug.st<double>(e, ug + alpha * (Uo.ld<double>(e) - ug));
+      }
+    }
+    const bool step_done = running && (fail || fin || iter >= a.max_iter);
+    __syncthreads();
 
-    for (int step = a.step_begin; step < a.step_end; ++step) {
-      const bool alive = valid && code == 0;
-      // target window: X_ref = X_targ[:, :T+1] for steps 0 and 1, then X_targ[:, step-1:...] (mpc.py:145,276)
-      const int w = step <= 1 ? 0 : step - 1;
-      Window win;
-      win.xbm = xt.shifted<cplx>((long)w * NX);
-      win.ubm = ut.shifted<double>((long)w * NU);
-      double lo0[NU], hi0[NU];
-#pragma unroll
-      for (int k = 0; k < NU; ++k) {
-        // u_prev = us[step-1] if step > 1 else U_ref[:, 0] (mpc.py:185)
-        const double up = step > 1 ? us.ld<double>((step - 1) * NU + k) : win.ubm.ld<double>(k);
-        const bool band = (a.flags & QP_DU_BAND) != 0;
-        lo0[k] = band ? up - a.du : -a.sat;
-        hi0[k] = band ? up + a.du : a.sat;
-      }
-      const bool use_ls = !(a.warm_start && step > 1);      // mpc.py:208-213
-      int iter = 0;
-      bool done = !alive;
-      while (__any(!done)) {
-        const bool act = !done;
-        const bool st = act && lane_ok;
-        riccati_backward<NX, NU>(prov, T, win, cost, a.flags, gains, j, st);
-        __syncthreads();
-        const double obj = rollout_forward<NX, NU>(prov, T, x_cur, win, cost, a.flags, gains, a.sat, lo0, hi0, Xo, Uo, j, st);
-        __syncthreads();
-        const bool fail = !finite_d(obj);                    // mpc.py:200-203
-        if (act) ++iter;
-        if (act && fail) { code = 3; done = true; }
-        const bool upd = act && !fail;
-        double alpha = 1.0;
-        bool fin = true;
-        if (use_ls) {
-          ZView<NX, NU> z;
-          z.T = T; z.Xg = Xg; z.Xo = Xo; z.Xt = win.xbm; z.Ug = Ug; z.Uo = Uo; z.Ut = win.ubm;
-          double stepn;
-          line_search<NX, NU>(z, a.Cq, a.Cqf, a.Cr, jj, alpha, stepn);
-          fin = stepn < a.ls_tol;                            // mpc.py:224
-        }
-        __syncthreads();
-        // X_guess += alpha (X_opt - X_guess) (mpc.py:228-229)
-        if (upd && lane_ok) {
-          for (int t = 0; t <= T; ++t) {
-            const cplx xg = Xg.ld<cplx>(t * NX + j), xo = Xo.ld<cplx>(t * NX + j);
-            Xg.st<cplx>(t * NX + j, mk(xg.re + alpha * (xo.re - xg.re), xg.im + alpha * (xo.im - xg.im)));
-          }
-        }
-        if (upd) {
-          for (int e = jj; e < T * NU; e += 16) {
-            const double ug = Ug.ld<double>(e);
-            Ug.st<double>(e, ug + alpha * (Uo.ld<double>(e) - ug));
-          }
-        }
-        if (upd && (fin || iter >= a.max_iter)) done = true;
-        __syncthreads();
-      }
-      if (alive && jj == 0) a.qp_solves[b * a.n_steps + step] = iter;
-      const bool ok = alive && code == 0;
+    // ---- rows that finished their MPC step: apply, propagate, shift ----
+    if (__any(step_done)) {
+      if (step_done && fail) code = 3;
+      if (step_done && jj == 0) a.qp_solves[b * a.n_steps + step] = iter;
+      const bool ok = step_done && !fail;
       // apply U_opt[:, 0] (mpc.py:250), propagate the plant (mpc.py:256-260)
       double uapp[NU];
 #pragma unroll
       for (int k = 0; k < NU; ++k) uapp[k] = Uo.ld<double>(k);
-      if (ok && jj == 0) {
+      if (ok) {
 #pragma unroll
-        for (int k = 0; k < NU; ++k) us.st<double>(step * NU + k, uapp[k]);
+        for (int k = 0; k < NU; ++k) uprev[k] = uapp[k];
+        if (jj == 0) {
+#pragma unroll
+          for (int k = 0; k < NU; ++k) a.us[b * sUs + (long)step * NU + k] = uapp[k];
+        }
       }
       if constexpr (PLANT == PLANT_HAMILTONIAN) {
         const cplx xn = plant_hamiltonian<NX, NU, DD>(x_cur, uapp, op0, ops, a.dt, scratch, j, jj);
         if (ok) x_cur = xn;
-        if (ok && lane_ok) xs.st<cplx>((step + 1) * NX + j, xn);
+        if (ok && lane_ok) a.xs[b * sXs + (long)(step + 1) * NX + j] = xn;
       } else if constexpr (PLANT == PLANT_GENERATOR) {
         const cplx xn = plant_generator<NX, NU>(x_cur, uapp, op0, ops, a.dt, j);
         if (ok) x_cur = xn;
-        if (ok && lane_ok) xs.st<cplx>((step + 1) * NX + j, xn);
+        if (ok && lane_ok) a.xs[b * sXs + (long)(step + 1) * NX + j] = xn;
       }
       // shift_guess (mpc.py:71-73,271-272): drop column 0, repeat the last
       if (ok && lane_ok) {
@@ -212,15 +247,33 @@ __global__ __launch_bounds__(64) M4Q_OCC void mpc_kernel(MpcArgs a) {
         for (int t = 0; t + 1 < T; ++t) Ug.st<double>(t * NU + jj, Ug.ld<double>((t + 1) * NU + jj));
       }
       if (ok) done_steps = step + 1;
+      if (step_done) {
+        iter = 0;
+        step = fail ? a.step_end : step + 1;
+      }
       __syncthreads();
       if constexpr (PLANT == PLANT_NONE) {
-        // the caller writes xs[step+1] before the next launch; nothing to carry inside this one
-        if (step + 1 < a.step_end) x_cur = xs.ld<cplx>((step + 1) * NX + j);
+        // the caller writes xs[step+1] before the next launch; inside one launch carry what is there
+        if (ok && step < a.step_end) x_cur = a.xs[b * sXs + (long)step * NX + j];
       }
     }
-    if (valid && jj == 0) {
-      a.codes[b] = code;
-      a.steps_done[b] = done_steps;
+
+    // ---- rows that finished their run: publish the resumable state, free the slot ----
+    const bool finished = active && step >= a.step_end;
+    if (__any(finished)) {
+      if (finished) {
+        if (lane_ok) {
+          for (int t = 0; t <= T; ++t) a.Xg[b * sX + t * NX + j] = Xg.ld<cplx>(t * NX + j);
+        }
+        for (int e = jj; e < T * NU; e += 16) a.Ug[b * sU + e] = Ug.ld<double>(e);
+        if (jj == 0) {
+          a.codes[b] = code;
+          a.steps_done[b] = done_steps;
+        }
+        active = false;
+        need_new = true;
+      }
+      __syncthreads();
     }
   }
 }
@@ -251,10 +304,11 @@ __global__ __launch_bounds__(64) M4Q_OCC void linearize_kernel(LinArgs a) {
     const GView Bo = gview(a.B_ls, q0 * sX * NU, gl * sX * NU);
     const GView Do = gview(a.D_ls, q0 * sX, gl * sX);
     for (int t = 0; t < a.T; ++t) {
+      const auto lin = prov.fetch(t);
       cplx Ac[NX];
-      prov.col(t, Ac);
+      prov.col(lin, Ac);
       cplx av, Brow[NU], dlt;
-      prov.rows(t, czero(), av, Brow, dlt);
+      prov.rows(lin, czero(), av, Brow, dlt);
       if (valid && L.lane_ok) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) Ao.st<cplx>((t * NX + i) * NX + j, Ac[i]);
@@ -308,7 +362,7 @@ __global__ __launch_bounds__(64) M4Q_OCC void qp_kernel(QpArgs a) {
       hi0[k] = band ? up + a.du : a.sat;
     }
     const cplx x0 = a.x_init[b * NX + j];
-    const double obj = rollout_forward<NX, NU>(prov, T, x0, win, cost, a.flags, gains, a.sat, lo0, hi0, Xo, Uo, j, st);
+    const double obj = rollout_forward<NX, NU, true>(prov, T, x0, win, cost, a.flags, gains, a.sat, lo0, hi0, Xo, Uo, j, st);
     if (valid && jj == 0) a.cost[b] = obj;
     __syncthreads();
   }
@@ -347,7 +401,7 @@ __global__ __launch_bounds__(64) M4Q_OCC void plant_kernel(PlantArgs a) {
 // ---------------------------------------------------------------------------------------------
 // host-side launchers for this shape
 // ---------------------------------------------------------------------------------------------
-static size_t mpc_lds_bytes() { return sizeof(double) * 2 * (size_t)(ROWS * MODEL_ELEMS + ROWS * SCRATCH_ELEMS); }
+static size_t mpc_lds_bytes() { return sizeof(double) * 2 * (size_t)(ROWS * MODEL_ELEMS + ROWS * SCRATCH_ELEMS + COST_ELEMS); }
 
 template <class K>
 static int prep_lds(K kern, size_t bytes) {

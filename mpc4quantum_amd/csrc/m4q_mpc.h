@@ -101,9 +101,10 @@ struct ModelPitch {
 };
 
 // ---------------------------------------------------------------------------------------------
-// Linearisation providers.  col(): column j of A_t.  rows(): for the row this lane owns,
-// (A_t v)_j for a distributed vector v, row j of B_t and Delta_t[j].
-// All views are positioned on this lane's instance; lane-dependent parts are 32-bit offsets.
+// Linearisation providers.  fetch(t): the per-t operands that come from memory (issued one horizon
+// index ahead of their use so the loads overlap the previous index's arithmetic).  col(): column j of
+// A_t.  rows(): for the row this lane owns, (A_t v)_j for a distributed vector v, row j of B_t and
+// Delta_t[j].  Views are positioned on this lane's instance; lane-dependent parts are 32-bit offsets.
 // ---------------------------------------------------------------------------------------------
 template <int NX, int NU, int ORDER>
 struct FusedProv {
@@ -114,16 +115,21 @@ struct FusedProv {
   GView Ug;           // [T][NU]
   int j;              // lane in row, clamped to NX-1
 
-  __device__ __forceinline__ void load_u(int t, double (&u)[NU]) const {
+  struct Lin {
+    double u[NU];
+    cplx xg;
+  };
+  __device__ __forceinline__ Lin fetch(int t) const {
+    Lin l;
 #pragma unroll
-    for (int k = 0; k < NU; ++k) u[k] = Ug.ld<double>(t * NU + k);
+    for (int k = 0; k < NU; ++k) l.u[k] = Ug.ld<double>(t * NU + k);
+    l.xg = Xg.ld<cplx>(t * NX + j);
+    return l;
   }
   // A_t = A + sum_p polyu_p N_p   (linearize.py:43-48)
-  __device__ __forceinline__ void col(int t, cplx (&Ac)[NX]) const {
-    double u[NU];
-    load_u(t, u);
+  __device__ __forceinline__ void col(const Lin& l, cplx (&Ac)[NX]) const {
     Poly<NU, ORDER> po;
-    po.eval(u);
+    po.eval(l.u);
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       cplx a = mdl[i * PITCH + j];
@@ -133,12 +139,9 @@ struct FusedProv {
     }
   }
   // B_t[:,k] = sum_p (N_p x) c_kp dmono_kp(u)  (linearize.py:50-59);  Delta_t = f - A_t x - B_t u = -B_t u (:68-69)
-  __device__ __forceinline__ void rows(int t, cplx v, cplx& av, cplx (&Brow)[NU], cplx& dlt) const {
-    double u[NU];
-    load_u(t, u);
+  __device__ __forceinline__ void rows(const Lin& l, cplx v, cplx& av, cplx (&Brow)[NU], cplx& dlt) const {
     Poly<NU, ORDER> po;
-    po.eval(u);
-    const cplx xg = Xg.ld<cplx>(t * NX + j);
+    po.eval(l.u);
     cplx nx[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) nx[p] = czero();
@@ -150,7 +153,7 @@ struct FusedProv {
       for (int p = 0; p < NP; ++p) {
         const cplx np = mdl[((1 + p) * NX + j) * PITCH + k];
         cmac_r(a, np, po.pu[p]);
-        cmac_bc<k>(nx[p], xg, np);
+        cmac_bc<k>(nx[p], l.xg, np);
       }
       cmac_bc<k>(av, v, a);
     });
@@ -161,7 +164,7 @@ struct FusedProv {
 #pragma unroll
       for (int p = 0; p < NP; ++p) cmac_r(b, nx[p], po.dpu[k][p]);
       Brow[k] = b;
-      cmac_r(dlt, b, -u[k]);
+      cmac_r(dlt, b, -l.u[k]);
     }
   }
 };
@@ -173,23 +176,28 @@ struct ExplicitProv {
   GView D_ls;   // [T][NX]
   bool has_delta;
   int j;
-  __device__ __forceinline__ void col(int t, cplx (&Ac)[NX]) const {
+  struct Lin {
+    int t;
+  };
+  __device__ __forceinline__ Lin fetch(int t) const { Lin l; l.t = t; return l; }
+  __device__ __forceinline__ void col(const Lin& l, cplx (&Ac)[NX]) const {
 #pragma unroll
-    for (int i = 0; i < NX; ++i) Ac[i] = A_ls.ld<cplx>((t * NX + i) * NX + j);
+    for (int i = 0; i < NX; ++i) Ac[i] = A_ls.ld<cplx>((l.t * NX + i) * NX + j);
   }
-  __device__ __forceinline__ void rows(int t, cplx v, cplx& av, cplx (&Brow)[NU], cplx& dlt) const {
+  __device__ __forceinline__ void rows(const Lin& l, cplx v, cplx& av, cplx (&Brow)[NU], cplx& dlt) const {
     av = czero();
     static_for<0, NX>([&](auto kk) {
       constexpr int k = decltype(kk)::value;
-      cmac_bc<k>(av, v, A_ls.ld<cplx>((t * NX + j) * NX + k));
+      cmac_bc<k>(av, v, A_ls.ld<cplx>((l.t * NX + j) * NX + k));
     });
 #pragma unroll
-    for (int k = 0; k < NU; ++k) Brow[k] = B_ls.ld<cplx>((t * NX + j) * NU + k);
-    dlt = has_delta ? D_ls.ld<cplx>(t * NX + j) : czero();
+    for (int k = 0; k < NU; ++k) Brow[k] = B_ls.ld<cplx>((l.t * NX + j) * NU + k);
+    dlt = has_delta ? D_ls.ld<cplx>(l.t * NX + j) : czero();
   }
 };
 
-// Stage costs (shared by the ensemble, wave-uniform pointers).  Q(t) for t < T, Qf at t == T; R(t).
+// Stage costs (shared by the ensemble, wave-uniform pointers; LDS in the fused kernel).
+// Q(t) for t < T, Qf at t == T; R(t).
 struct CostRef {
   const cplx* Q;
   const cplx* Qf;
@@ -215,8 +223,7 @@ struct Window {
 // gains layout: [t][col 0..NX][NU]  (col NX holds k); the view is positioned at the instance.
 // ---------------------------------------------------------------------------------------------
 #define M4Q_PHASE() __builtin_amdgcn_sched_barrier(0)
-// the LDS model and the shared cost matrices are loop invariant; without this the compiler hoists
-// their loads out of the horizon loops and keeps (then spills) hundreds of VGPRs of them
+// keeps loop-invariant LDS/global loads inside the horizon loops (hoisted, they cost hundreds of VGPRs)
 #define M4Q_NO_HOIST() asm volatile("" ::: "memory")
 
 template <int NX, int NU, class Prov>
@@ -225,30 +232,39 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
   const bool ref = (flags & QP_REF_LQR) != 0;
   cplx Pc[NX];
   cplx pv = czero();
+  cplx xb_next = win.xbm.ld<cplx>(T * NX + j);        // xbar_{t+1} of the first iteration
   {
     const cplx* Qt = cost.q(T, T);
 #pragma unroll
     for (int i = 0; i < NX; ++i) Pc[i] = Qt[i * NX + j];
     if (ref) {
-      const cplx r = win.xbm.ld<cplx>(T * NX + j);
       static_for<0, NX>([&](auto ii) {
         constexpr int i = decltype(ii)::value;
-        cmac_bc<i>(pv, r, cneg(Qt[j * NX + i]));
+        cmac_bc<i>(pv, xb_next, cneg(Qt[j * NX + i]));
       });
     }
   }
+  // operands of horizon index t are fetched while index t+1 is being worked on
+  typename Prov::Lin lin = prov.fetch(T - 1);
+  cplx xb = win.xbm.ld<cplx>((T - 1) * NX + j);
+  double ub[NU];
+#pragma unroll
+  for (int k = 0; k < NU; ++k) ub[k] = win.ubm.ld<double>((T - 1) * NU + k);
   for (int t = T - 1; t >= 0; --t) {
     M4Q_NO_HOIST();
-    cplx Ac[NX];
-    prov.col(t, Ac);
-    M4Q_PHASE();
-    const cplx xb = win.xbm.ld<cplx>(t * NX + j);
-    const cplx xb1 = win.xbm.ld<cplx>((t + 1) * NX + j);
-    double ub[NU];
+    const int tn = t > 0 ? t - 1 : 0;
+    const typename Prov::Lin lin_n = prov.fetch(tn);
+    const cplx xb_n = win.xbm.ld<cplx>(tn * NX + j);
+    double ub_n[NU];
 #pragma unroll
-    for (int k = 0; k < NU; ++k) ub[k] = win.ubm.ld<double>(t * NU + k);
+    for (int k = 0; k < NU; ++k) ub_n[k] = win.ubm.ld<double>(tn * NU + k);
+
+    cplx Ac[NX];
+    prov.col(lin, Ac);
+    M4Q_PHASE();
+    const cplx xb1 = xb_next;
     cplx ax, Brow[NU], dlt;
-    prov.rows(t, xb, ax, Brow, dlt);
+    prov.rows(lin, xb, ax, Brow, dlt);
     M4Q_PHASE();
 
     // affine column of the augmented dynamics
@@ -366,15 +382,23 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
 #pragma unroll
     for (int i = 0; i < NX; ++i) Pc[i] = Pn[i];
     pv = pn;
+    // rotate the prefetched operands in
+    xb_next = xb;
+    xb = xb_n;
+    lin = lin_n;
+#pragma unroll
+    for (int k = 0; k < NU; ++k) ub[k] = ub_n[k];
     M4Q_PHASE();
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Forward rollout with clipping (lqr.py:67-79; dynamics with Delta: optimize.py:41).
-// x distributed (lane j holds x_t[j]).  Returns the objective, replicated over the row.
+// x distributed (lane j holds x_t[j]).  WANT_COST: return the objective (replicated over the row);
+// otherwise return sum |x|^2 + sum u^2, which is finite exactly when every state and control is -
+// all the closed loop needs for its exit code 3 (mpc.py:200-203).
 // ---------------------------------------------------------------------------------------------
-template <int NX, int NU, class Prov>
+template <int NX, int NU, bool WANT_COST, class Prov>
 __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, cplx x0, const Window& win, const CostRef& cost,
                                                    int flags, const GView& gains, double sat, const double (&lo0)[NU],
                                                    const double (&hi0)[NU], const GView& Xo, const GView& Uo, int j,
@@ -384,29 +408,39 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, cplx 
   if (store_ok) Xo.st<cplx>(j, x);
   double cx = 0.0;     // per-lane share of the state cost
   double cu = 0.0;     // control cost (replicated)
-  for (int t = 0; t < T; ++t) {
-    M4Q_NO_HOIST();
-    const cplx xb = win.xbm.ld<cplx>(t * NX + j);
+  struct Ops {
+    typename Prov::Lin lin;
+    cplx xb;
     double ub[NU];
-#pragma unroll
-    for (int k = 0; k < NU; ++k) ub[k] = win.ubm.ld<double>(t * NU + k);
-    const unsigned gt = (unsigned)t * (NX + 1) * NU;
     cplx Kx[NU];
     double kre[NU];
+  };
+  auto load = [&](int t) {
+    Ops o;
+    o.lin = prov.fetch(t);
+    o.xb = win.xbm.ld<cplx>(t * NX + j);
+    const unsigned gt = (unsigned)t * (NX + 1) * NU;
 #pragma unroll
     for (int k = 0; k < NU; ++k) {
-      Kx[k] = gains.ld<cplx>(gt + j * NU + k);
-      kre[k] = gains.ld<cplx>(gt + NX * NU + k).re;
+      o.ub[k] = win.ubm.ld<double>(t * NU + k);
+      o.Kx[k] = gains.ld<cplx>(gt + j * NU + k);
+      o.kre[k] = gains.ld<cplx>(gt + NX * NU + k).re;
     }
+    return o;
+  };
+  Ops cur = load(0);
+  for (int t = 0; t < T; ++t) {
+    M4Q_NO_HOIST();
+    const Ops nxt = load(t + 1 < T ? t + 1 : t);
     cplx ax, Brow[NU], dlt;
-    prov.rows(t, x, ax, Brow, dlt);
+    prov.rows(cur.lin, x, ax, Brow, dlt);
     M4Q_PHASE();
-    const cplx dx = csub(x, xb);
+    const cplx dx = csub(x, cur.xb);
     double u[NU];
 #pragma unroll
     for (int k = 0; k < NU; ++k) {
-      const double part = Kx[k].re * dx.re - Kx[k].im * dx.im;
-      double uk = rowsum<NX>(part) + kre[k] + ub[k];                   // lqr.py:75
+      const double part = cur.Kx[k].re * dx.re - cur.Kx[k].im * dx.im;
+      double uk = rowsum<NX>(part) + cur.kre[k] + cur.ub[k];           // lqr.py:75
       double lo = -sat, hi = sat;
       if (t == 0) {
         lo = fmax(lo, lo0[k]);
@@ -418,9 +452,8 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, cplx 
     cplx xn = ref ? ax : cadd(ax, dlt);
 #pragma unroll
     for (int k = 0; k < NU; ++k) cmac_r(xn, Brow[k], u[k]);
-    // objective
-    const cplx* Rt = cost.r(t);
-    {
+    if constexpr (WANT_COST) {
+      const cplx* Rt = cost.r(t);
       const cplx e = ref ? xn : dx;
       const cplx* Qt = cost.q(ref ? t + 1 : t, T);
       cplx qe = czero();
@@ -433,11 +466,15 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, cplx 
       for (int k = 0; k < NU; ++k) {
 #pragma unroll
         for (int l = 0; l < NU; ++l) {
-          const double ek = ref ? u[k] : u[k] - ub[k];
-          const double el = ref ? u[l] : u[l] - ub[l];
+          const double ek = ref ? u[k] : u[k] - cur.ub[k];
+          const double el = ref ? u[l] : u[l] - cur.ub[l];
           cu += ek * Rt[k * NU + l].re * el;
         }
       }
+    } else {
+      cx = fma(xn.re, xn.re, fma(xn.im, xn.im, cx));
+#pragma unroll
+      for (int k = 0; k < NU; ++k) cu = fma(u[k], u[k], cu);
     }
     x = xn;
     if (store_ok) {
@@ -447,17 +484,20 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, cplx 
         for (int k = 0; k < NU; ++k) Uo.st<double>(t * NU + k, u[k]);
       }
     }
+    cur = nxt;
     M4Q_PHASE();
   }
-  if (!ref) {
-    const cplx e = csub(x, win.xbm.ld<cplx>(T * NX + j));
-    const cplx* Qt = cost.q(T, T);
-    cplx qe = czero();
-    static_for<0, NX>([&](auto ii) {
-      constexpr int i = decltype(ii)::value;
-      cmac_bc<i>(qe, e, Qt[j * NX + i]);
-    });
-    cx += e.re * qe.re + e.im * qe.im;
+  if constexpr (WANT_COST) {
+    if (!ref) {
+      const cplx e = csub(x, win.xbm.ld<cplx>(T * NX + j));
+      const cplx* Qt = cost.q(T, T);
+      cplx qe = czero();
+      static_for<0, NX>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        cmac_bc<i>(qe, e, Qt[j * NX + i]);
+      });
+      cx += e.re * qe.re + e.im * qe.im;
+    }
   }
   return rowsum<NX>(cx) + cu;
 }
