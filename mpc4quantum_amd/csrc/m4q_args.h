@@ -17,6 +17,7 @@ struct MpcArgs {
   const double* u_targ; long ut_stride;     // [B|1][cols][m]
   const cplx* Q; const cplx* Qf; const cplx* R;
   const double* Cq; const double* Cqf; const double* Cr;   // line-search blocks (mpc.py:103-116)
+  const double* Wls;                        // [2n + 2n + 2m] diagonals of those blocks, or nullptr if one is not diagonal
   const cplx* op0; long op0_stride;         // plant operators
   const cplx* ops; long ops_stride;
   cplx* xs; double* us; int* codes; int* steps_done; int* qp_solves;

@@ -111,12 +111,13 @@ struct m4q_session {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int grid = 1;
   DevBuf f[M4Q_F_COUNT];
-  DevBuf Cq, Cqf, Cr, wsXg, wsUg, wsXo, wsUo, wsG, queue;
+  DevBuf Cq, Cqf, Cr, Wls, wsXg, wsUg, wsXo, wsUo, wsG, queue;
   size_t fbytes[M4Q_F_COUNT]{};
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
   double ms_total = 0.0;
   int launches = 0;
   bool costs_dirty = true;
+  bool ls_diag = false;
   std::vector<double> hQ, hQf, hR;
 };
 
@@ -219,6 +220,7 @@ int m4q_session_create(const m4q_problem* p, int32_t B, int32_t device, m4q_sess
   if (!rc) rc = s->Cq.alloc(4 * n * n * 8);
   if (!rc) rc = s->Cqf.alloc(4 * n * n * 8);
   if (!rc) rc = s->Cr.alloc(4 * m * m * 8);
+  if (!rc) rc = s->Wls.alloc((4 * n + 2 * m) * 8);
   if (rc) { m4q_session_destroy(s); return rc; }
   for (int i : {M4Q_F_XS, M4Q_F_US, M4Q_F_CODES, M4Q_F_STEPS_DONE, M4Q_F_QP_SOLVES})
     HIP_TRY(hipMemsetAsync(s->f[i].p, 0, fb[i], s->stream));
@@ -300,13 +302,26 @@ static int refresh_costs(m4q_session* s) {
   if (!s->costs_dirty) return 0;
   const int n = s->prob.dim_x, m = s->prob.dim_u;
   if (s->hQ.empty() || s->hQf.empty() || s->hR.empty()) return fail(M4Q_E_BADARG, "Q, Qf and R must be uploaded before running");
-  std::vector<double> c;
+  std::vector<double> c, w;
+  bool diag = true;
+  auto take_diag = [&](int k) {
+    const int sz = 2 * k;
+    for (int i = 0; i < sz; ++i)
+      for (int j2 = 0; j2 < sz; ++j2)
+        if (i != j2 && c[(size_t)i * sz + j2] != 0.0) diag = false;
+    for (int i = 0; i < sz; ++i) w.push_back(c[(size_t)i * sz + i]);
+  };
   ls_block(s->hQ.data(), n, c);
   HIP_TRY(hipMemcpy(s->Cq.p, c.data(), c.size() * 8, hipMemcpyHostToDevice));
+  take_diag(n);
   ls_block(s->hQf.data(), n, c);
   HIP_TRY(hipMemcpy(s->Cqf.p, c.data(), c.size() * 8, hipMemcpyHostToDevice));
+  take_diag(n);
   ls_block(s->hR.data(), m, c);
   HIP_TRY(hipMemcpy(s->Cr.p, c.data(), c.size() * 8, hipMemcpyHostToDevice));
+  take_diag(m);
+  HIP_TRY(hipMemcpy(s->Wls.p, w.data(), w.size() * 8, hipMemcpyHostToDevice));
+  s->ls_diag = diag;
   s->costs_dirty = false;
   return 0;
 }
@@ -329,6 +344,7 @@ int m4q_session_run(m4q_session* s, int32_t step_begin, int32_t step_end) {
   a.u_targ = (const double*)s->f[M4Q_F_U_TARG].p; a.ut_stride = p.target_per_instance ? (long)(p.target_cols * m) : 0;
   a.Q = (const cplx*)s->f[M4Q_F_Q].p; a.Qf = (const cplx*)s->f[M4Q_F_QF].p; a.R = (const cplx*)s->f[M4Q_F_R].p;
   a.Cq = (const double*)s->Cq.p; a.Cqf = (const double*)s->Cqf.p; a.Cr = (const double*)s->Cr.p;
+  a.Wls = s->ls_diag ? (const double*)s->Wls.p : nullptr;
   a.op0 = (const cplx*)s->f[M4Q_F_OP0].p; a.op0_stride = p.plant_per_instance ? (long)(k * k) : 0;
   a.ops = (const cplx*)s->f[M4Q_F_OPS].p; a.ops_stride = p.plant_per_instance ? (long)(m * k * k) : 0;
   if (p.plant_kind == M4Q_PLANT_NONE) { a.op0 = a.Q; a.ops = a.Q; a.op0_stride = a.ops_stride = 0; }

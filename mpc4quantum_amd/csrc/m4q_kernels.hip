@@ -71,6 +71,7 @@ struct LaneGeo {
 // the pace of its slowest member and a static split leaves the slowest wave 1.6x the mean.
 // ---------------------------------------------------------------------------------------------
 constexpr int COST_ELEMS = 2 * NX * NX + NU * NU;         // Q, Qf, R staged in LDS once per workgroup
+constexpr int WLS_DOUBLES = 4 * NX + 2 * NU;               // diagonal line-search weights, staged after them
 
 __device__ __forceinline__ int row_bcast_int(int v) { return __shfl(v, 0, 16); }
 
@@ -86,6 +87,11 @@ __global__ __launch_bounds__(64) M4Q_OCC void mpc_kernel(MpcArgs a) {
   cplx* ldsQ = lds + ROWS * (MODEL_ELEMS + SCRATCH_ELEMS);
   for (int e = threadIdx.x; e < COST_ELEMS; e += 64)
     ldsQ[e] = e < NX * NX ? a.Q[e] : (e < 2 * NX * NX ? a.Qf[e - NX * NX] : a.R[e - 2 * NX * NX]);
+  double* ldsW = reinterpret_cast<double*>(ldsQ + COST_ELEMS);
+  const bool ls_diag = a.Wls != nullptr;
+  if (ls_diag) {
+    for (int e = threadIdx.x; e < WLS_DOUBLES; e += 64) ldsW[e] = a.Wls[e];
+  }
   CostRef cost;
   cost.Q = ldsQ; cost.Qf = ldsQ + NX * NX; cost.q_stride = 0; cost.R = ldsQ + 2 * NX * NX; cost.r_stride = 0;
   // workspace of this resident row: wave-uniform base per workgroup, lane part = row within the wave
@@ -187,7 +193,8 @@ __global__ __launch_bounds__(64) M4Q_OCC void mpc_kernel(MpcArgs a) {
       ZView<NX, NU> z;
       z.T = T; z.Xg = Xg; z.Xo = Xo; z.Xt = win.xbm; z.Ug = Ug; z.Uo = Uo; z.Ut = win.ubm;
       double al, stepn;
-      line_search<NX, NU>(z, a.Cq, a.Cqf, a.Cr, jj, al, stepn);
+      if (ls_diag) line_search_diag<NX, NU>(z, ldsW, ldsW + 2 * NX, ldsW + 4 * NX, jj, al, stepn);
+      else line_search<NX, NU>(z, a.Cq, a.Cqf, a.Cr, jj, al, stepn);
       if (use_ls) { alpha = al; fin = stepn < a.ls_tol; }   // mpc.py:224
     }
     __syncthreads();
@@ -401,7 +408,9 @@ __global__ __launch_bounds__(64) M4Q_OCC void plant_kernel(PlantArgs a) {
 // ---------------------------------------------------------------------------------------------
 // host-side launchers for this shape
 // ---------------------------------------------------------------------------------------------
-static size_t mpc_lds_bytes() { return sizeof(double) * 2 * (size_t)(ROWS * MODEL_ELEMS + ROWS * SCRATCH_ELEMS + COST_ELEMS); }
+static size_t mpc_lds_bytes() {
+  return sizeof(double) * (2 * (size_t)(ROWS * MODEL_ELEMS + ROWS * SCRATCH_ELEMS + COST_ELEMS) + WLS_DOUBLES + 2);
+}
 
 template <class K>
 static int prep_lds(K kern, size_t bytes) {

@@ -577,6 +577,55 @@ __device__ __forceinline__ void ls_block(const ZV& z, int base, const double* C,
   }
 }
 
+// Fast path when every cost block is diagonal (real diagonal Q, Qf, R - the case of all reference
+// scenarios): the block products collapse to one weight per Z entry.  Each lane walks ITS state element
+// over the horizon in natural (coalesced) order and looks the weight of the Z slot that element lands in
+// up in a 2n-entry table, so the reference's layout quirk costs two integer divisions per element.
+// wq/wqf: 2*NX weights, wr: 2*NU weights (LDS or L1-resident).
+template <int NX, int NU>
+__device__ __forceinline__ void line_search_diag(const ZView<NX, NU>& z, const double* wq, const double* wqf,
+                                                 const double* wr, int jj, double& alpha, double& step_norm) {
+  const int T = z.T;
+  const int nxt = NX * (T + 1);
+  double num = 0.0, den = 0.0, nrm = 0.0;
+  if (jj < NX) {
+    for (int t = 0; t <= T; ++t) {
+      const cplx g = z.Xg.template ld<cplx>(t * NX + jj), o = z.Xo.template ld<cplx>(t * NX + jj),
+                 tg = z.Xt.template ld<cplx>(t * NX + jj);
+      const int q0 = jj * (T + 1) + t;          // Z slot of the real part; the imaginary part sits nxt further
+#pragma unroll
+      for (int part = 0; part < 2; ++part) {
+        const int q = q0 + part * nxt;
+        const int blk = q / (2 * NX);
+        const int r = q - blk * (2 * NX);
+        const double w = (blk == T ? wqf : wq)[r];
+        const double e = part ? g.im - tg.im : g.re - tg.re;
+        const double d = part ? o.im - g.im : o.re - g.re;
+        num = fma(w * e, d, num);
+        den = fma(w * d, d, den);
+        nrm = fma(d, d, nrm);
+      }
+    }
+  }
+  // controls: Z = [U.flatten() (k-major over (m, T)), zeros]; block b covers 2m consecutive slots
+  for (int f = jj; f < NU * T; f += 16) {
+    const int k = f / T;
+    const int t = f - k * T;
+    const double g = z.Ug.template ld<double>(t * NU + k), o = z.Uo.template ld<double>(t * NU + k),
+                 tg = z.Ut.template ld<double>(t * NU + k);
+    const double w = wr[f % (2 * NU)];
+    const double e = g - tg, d = o - g;
+    num = fma(w * e, d, num);
+    den = fma(w * d, d, den);
+    nrm = fma(d, d, nrm);
+  }
+  num = rowsum<16>(num);
+  den = rowsum<16>(den);
+  nrm = rowsum<16>(nrm);
+  alpha = -num / den;
+  step_norm = fabs(alpha) * sqrt(nrm);
+}
+
 template <int NX, int NU>
 __device__ __forceinline__ void line_search(const ZView<NX, NU>& z, const double* Cq, const double* Cqf,
                                             const double* Cr, int jj, double& alpha, double& step_norm) {

@@ -388,6 +388,25 @@ def test_closed_loop_full_horizon_config3_sample():
     assert np.all(np.abs(res["xs"] - xs).max(axis=(0, 1))[1:] <= 1e-9 + 100 * ex[1:])
 
 
+def test_closed_loop_dense_costs_general_line_search():
+    """Hermitian Q, Qf with complex off-diagonal entries and a non-diagonal R: exercises the dense-block line
+    search (the diagonal fast path is what every reference scenario takes) and the full Q terms of the sweep."""
+    p = configs.build(3, batch=3, horizon=10, n_steps=5)
+    rng = np.random.default_rng(11)
+    M = rng.standard_normal((9, 9)) + 1j * rng.standard_normal((9, 9))
+    p["Q"] = p["Q"] + 0.05 * (M @ M.conj().T)
+    M = rng.standard_normal((9, 9)) + 1j * rng.standard_normal((9, 9))
+    p["Qf"] = 2 * p["Q"] + 0.05 * (M @ M.conj().T)
+    p["R"] = p["R"] @ np.array([[1.0, 0.3], [0.3, 2.0]])
+    p["R"] = 0.5 * (p["R"] + p["R"].T)
+    idx = np.arange(3)
+    res = _gpu_batch(p, idx)
+    xs, us, codes, solves = _oracle_batch(p, idx)
+    assert np.array_equal(res["qp_solves"], solves)
+    assert rel(res["us"][:, :, 0], us[:, :, 0]) <= 1e-10 and rel(res["xs"][:, :, 1], xs[:, :, 1]) <= 1e-10
+    assert rel(res["us"], us) <= 1e-6 and rel(res["xs"], xs) <= 1e-6
+
+
 def test_closed_loop_no_warm_start_and_max_iter():
     p = configs.build(1, batch=1)
     res = _gpu_batch(p, np.arange(1), warm_start=False, max_iter=3)
