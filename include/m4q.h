@@ -52,6 +52,12 @@ extern "C" {
 #define M4Q_PLANT_HAMILTONIAN 1 /* rho+ = U rho U^H, U = expm(-i dt (H0 + sum_k u_k H_k)), d x d operators */
 #define M4Q_PLANT_GENERATOR 2   /* x+ = expm(dt (L0 + sum_k u_k L_k)) x, n x n operators */
 
+/* options (m4q_problem.reserved).  By default a session whose model, states, targets and costs are real in a
+ * Hermitian operator basis (every vectorised-Liouvillian model and Hermitian state is) runs the closed loop in
+ * that basis with real arithmetic - a quarter of the flops of the complex recursion of lqr.py, same results to
+ * rounding; anything else runs the general complex path.  This bit forces the complex path. */
+#define M4Q_OPT_FORCE_COMPLEX 1
+
 /* exit codes per instance (mpc.py:130,195,202,291): 0 normal, 1 exit_condition (host side),
  * 2 reserved (solver warning: cannot occur without OSQP), 3 non-finite objective */
 
@@ -69,7 +75,7 @@ typedef struct m4q_problem {
   int32_t plant_per_instance;
   int32_t target_per_instance;
   int32_t target_cols; /* columns of X_targ; U_targ has the same count (extra ones unused) */
-  int32_t reserved;
+  int32_t reserved;    /* options: bit 0 = M4Q_OPT_FORCE_COMPLEX */
   double dt;     /* StepClock.dt */
   double sat;    /* |u| <= sat (optimize.py:43, lqr.py:76) */
   double du;     /* first-control band (optimize.py:29-30); ignored without M4Q_QP_DU_BAND */
@@ -168,6 +174,8 @@ M4Q_API int m4q_session_sync(m4q_session* s);
 M4Q_API int m4q_session_set_codes(m4q_session* s, const int32_t* codes);
 /* kernel time of the launches since the last call, from HIP events on the session stream */
 M4Q_API int m4q_session_kernel_ms(m4q_session* s, double* total_ms, int32_t* launches);
+/* 1 if the uploaded problem qualifies for (and will run on) the real-arithmetic path, else 0 */
+M4Q_API int m4q_session_path(const m4q_session* s);
 /* resident bytes and launch geometry, for reports */
 M4Q_API int m4q_session_info(const m4q_session* s, int64_t* hbm_bytes, int32_t* grid, int32_t* lds_bytes);
 

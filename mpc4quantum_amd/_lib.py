@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libm4q_hip.so")
 
 QP_REF_LQR = 1
 QP_DU_BAND = 2
+OPT_FORCE_COMPLEX = 1
 PLANT_NONE, PLANT_HAMILTONIAN, PLANT_GENERATOR = 0, 1, 2
 E_UNSUPPORTED, E_BADARG, E_NODEVICE = -1001, -1002, -1003
 
@@ -67,6 +68,7 @@ PROTOTYPES = {
     "m4q_session_set_codes": (C.c_int, [_vp, _ip]),
     "m4q_session_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_double), _ip]),
     "m4q_session_info": (C.c_int, [_vp, C.POINTER(C.c_int64), _ip, _ip]),
+    "m4q_session_path": (C.c_int, [_vp]),
 }
 
 _lib = None

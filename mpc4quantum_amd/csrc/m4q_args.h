@@ -8,22 +8,25 @@ namespace m4q {
 
 struct cplx;
 
+// Arrays marked S are complex (cplx) on the general path and double on the real path (models that preserve
+// Hermiticity, expressed in the Hermitian operator basis of m4q_mpc.h); the host picks the kernel.
 struct MpcArgs {
   int B, T, n_steps, max_iter, warm_start, flags, step_begin, step_end;
   double dt, sat, du, ls_tol;
-  const cplx* models;  long model_stride;   // [B|1][n][n(1+P)]
-  const cplx* x0;                           // [B][n]
-  const cplx* x_targ;  long xt_stride;      // [B|1][cols][n]
+  const void* models;  long model_stride;   // S [B|1][n][n(1+P)]
+  const cplx* x0c;                          // [B][n] complex, as given (becomes xs[:, 0])
+  const void* x0s;                          // S [B][n]
+  const void* x_targ;  long xt_stride;      // S [B|1][cols][n]
   const double* u_targ; long ut_stride;     // [B|1][cols][m]
-  const cplx* Q; const cplx* Qf; const cplx* R;
+  const void* Q; const void* Qf; const void* R;            // S
   const double* Cq; const double* Cqf; const double* Cr;   // line-search blocks (mpc.py:103-116)
   const double* Wls;                        // [2n + 2n + 2m] diagonals of those blocks, or nullptr if one is not diagonal
   const cplx* op0; long op0_stride;         // plant operators
   const cplx* ops; long ops_stride;
   cplx* xs; double* us; int* codes; int* steps_done; int* qp_solves;
-  cplx* Xg; double* Ug;                     // per-instance SQP guess  [B][T+1][n], [B][T][m] (resumable state)
-  // per resident row (grid*4 of them): working guess, QP solution, gains
-  cplx* ws_Xg; double* ws_Ug; cplx* ws_Xo; double* ws_Uo; cplx* ws_gains;
+  cplx* Xg; double* Ug;                     // per-instance SQP guess  [B][T+1][n] complex, [B][T][m] (resumable state)
+  // per resident row (grid*4 of them): working guess, QP solution, gains (S)
+  void* ws_Xg; double* ws_Ug; void* ws_Xo; double* ws_Uo; void* ws_gains;
   int* queue;                               // next instance to hand out; zeroed before every launch
 };
 
@@ -58,13 +61,13 @@ struct PlantArgs {
 // one entry per compiled (dim_x, dim_u, order)
 struct ShapeOps {
   int nx, nu, order, np, d;
-  size_t (*mpc_lds_bytes)();
-  int (*launch_mpc)(const MpcArgs&, int plant_kind, int grid, hipStream_t);
+  size_t (*mpc_lds_bytes)(int real_path);
+  int (*launch_mpc)(const MpcArgs&, int plant_kind, int real_path, int grid, hipStream_t);
   int (*launch_linearize)(const LinArgs&, hipStream_t);
   int (*launch_qp)(const QpArgs&, hipStream_t);
   int (*launch_plant)(const PlantArgs&, hipStream_t);
   int (*power_list)(int32_t* out);
-  int (*occupancy)(int plant_kind);         // resident workgroups per CU of the fused kernel
+  int (*occupancy)(int plant_kind, int real_path);   // resident workgroups per CU of the fused kernel
 };
 
 }  // namespace m4q

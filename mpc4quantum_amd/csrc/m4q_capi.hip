@@ -2,7 +2,10 @@
 // Owns device memory, streams and events; dispatches to the per-shape kernel objects.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <complex>
+#include <cstdlib>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -100,6 +103,58 @@ void ls_block(const double* M, int k, std::vector<double>& out) {
     for (int j = 0; j < s; ++j) out[(size_t)i * s + j] = 0.5 * (c[(size_t)i * s + j] + c[(size_t)j * s + i]);
 }
 
+
+// ---- Hermitian operator basis of the real path (same convention as csrc/m4q_mpc.h) ----------------
+// slot c = a*d + b:  a == b: rho_aa;  a < b: sqrt2 Re rho_ab;  a > b: sqrt2 Im rho_ab.
+// Column c of the unitary W (x = W r) has at most two entries; (W^H v)_c and (M W)_{.,c} cost O(1).
+struct HermBasis {
+  int d, n;
+  explicit HermBasis(int d_) : d(d_), n(d_ * d_) {}
+  // out = W^H v  (complex n-vector, stride 1)
+  void lift_vec(const std::complex<double>* v, std::complex<double>* out) const {
+    const double rs = 0.70710678118654752440;
+    const std::complex<double> I(0, 1);
+    for (int a = 0; a < d; ++a)
+      for (int b = 0; b < d; ++b) {
+        const int c = a * d + b, ct = b * d + a;
+        if (a == b) out[c] = v[c];
+        else if (a < b) out[c] = (v[c] + v[ct]) * rs;            // conj(1/sqrt2) (x_ab + x_ba)
+        else out[c] = (v[c] - v[ct]) * (-I * rs);                // conj(+i/sqrt2) x_ab + conj(-i/sqrt2) x_ba
+      }
+  }
+  // M (n x n, row-major, leading dimension ld) -> W^H M W, written to out (n x n, leading dimension ldo)
+  void lift_mat(const std::complex<double>* M, long ld, std::complex<double>* out, long ldo) const {
+    const double rs = 0.70710678118654752440;
+    const std::complex<double> I(0, 1);
+    std::vector<std::complex<double>> Y((size_t)n * n);
+    for (int i = 0; i < n; ++i)
+      for (int a = 0; a < d; ++a)
+        for (int b = 0; b < d; ++b) {
+          const int c = a * d + b, ct = b * d + a;
+          const std::complex<double> m1 = M[i * ld + c], m2 = M[i * ld + ct];
+          if (a == b) Y[(size_t)i * n + c] = m1;
+          else if (a < b) Y[(size_t)i * n + c] = (m1 + m2) * rs;
+          else Y[(size_t)i * n + c] = (m1 - m2) * (I * rs);      // W[(a,b),c] = +i/sqrt2, W[(b,a),c] = -i/sqrt2
+        }
+    std::vector<std::complex<double>> col(n), lifted(n);
+    for (int j = 0; j < n; ++j) {
+      for (int i = 0; i < n; ++i) col[i] = Y[(size_t)i * n + j];
+      lift_vec(col.data(), lifted.data());
+      for (int i = 0; i < n; ++i) out[i * ldo + j] = lifted[i];
+    }
+  }
+};
+
+// real part of a lifted array + the size of what was dropped, relative to the array's scale
+struct LiftStat {
+  double max_im = 0.0, max_abs = 0.0;
+  void see(std::complex<double> v) {
+    max_im = std::max(max_im, std::fabs(v.imag()));
+    max_abs = std::max(max_abs, std::abs(v));
+  }
+  bool real_enough() const { return max_im <= 1e-13 * std::max(1.0, max_abs); }
+};
+
 }  // namespace
 
 struct m4q_session {
@@ -118,6 +173,14 @@ struct m4q_session {
   int launches = 0;
   bool costs_dirty = true;
   bool ls_diag = false;
+  // real path: inputs lifted to the Hermitian operator basis at upload time (doubles), and whether each was real there
+  DevBuf r_models, r_x0, r_xtarg, r_Q, r_Qf, r_R;
+  bool herm_ok[M4Q_F_COUNT] = {};
+  bool force_complex = false;
+  bool use_real() const {
+    return !force_complex && ls_diag && herm_ok[M4Q_F_MODELS] && herm_ok[M4Q_F_X0] && herm_ok[M4Q_F_X_TARG] &&
+           herm_ok[M4Q_F_Q] && herm_ok[M4Q_F_QF] && herm_ok[M4Q_F_R];
+  }
   std::vector<double> hQ, hQf, hR;
 };
 
@@ -176,6 +239,7 @@ int m4q_session_create(const m4q_problem* p, int32_t B, int32_t device, m4q_sess
   s->prob = *p;
   s->B = B;
   s->shape = sh;
+  s->force_complex = (p->reserved & 1) != 0 || std::getenv("M4Q_FORCE_COMPLEX") != nullptr;
   HIP_TRY(hipGetDevice(&s->device));
   HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&s->ev0));
@@ -205,7 +269,8 @@ int m4q_session_create(const m4q_problem* p, int32_t B, int32_t device, m4q_sess
   // resident grid: as many workgroups as the device holds at once (persistent, quad-strided)
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, s->device));
-  int per_cu = sh->occupancy(p->plant_kind);
+  // the grid (and the per-row workspace) is sized for whichever path keeps more workgroups resident
+  int per_cu = std::max(sh->occupancy(p->plant_kind, 0), s->force_complex ? 0 : sh->occupancy(p->plant_kind, 1));
   if (per_cu < 1) per_cu = 1;
   const int nquads = (B + 3) / 4;
   long resident = (long)per_cu * prop.multiProcessorCount;
@@ -243,17 +308,81 @@ size_t m4q_session_field_bytes(const m4q_session* s, int32_t field) {
   return s->fbytes[field];
 }
 
+// lift one uploaded input to the Hermitian basis: keeps the real part on the device (doubles), remembers whether the
+// imaginary part was negligible.  vec_len = n for vectors; matrices are n x n blocks laid side by side (nblk per row set).
+static int lift_upload(m4q_session* s, int32_t field, const std::complex<double>* src, size_t count_items, bool matrix, int nblk,
+                       DevBuf& dst) {
+  const HermBasis hb(s->shape->d);
+  const int n = hb.n;
+  LiftStat st;
+  std::vector<double> out;
+  if (!matrix) {
+    out.resize(count_items * n);
+    std::vector<std::complex<double>> tmp(n);
+    for (size_t it = 0; it < count_items; ++it) {
+      hb.lift_vec(src + it * n, tmp.data());
+      for (int i = 0; i < n; ++i) { st.see(tmp[i]); out[it * n + i] = tmp[i].real(); }
+    }
+  } else {
+    // count_items matrices of shape n x (n * nblk), row-major: block p occupies columns [p*n, (p+1)*n)
+    const long ld = (long)n * nblk;
+    out.resize(count_items * n * ld);
+    std::vector<std::complex<double>> tmp((size_t)n * n);
+    for (size_t it = 0; it < count_items; ++it)
+      for (int p = 0; p < nblk; ++p) {
+        hb.lift_mat(src + it * n * ld + (long)p * n, ld, tmp.data(), n);
+        for (int i = 0; i < n; ++i)
+          for (int j = 0; j < n; ++j) {
+            st.see(tmp[(size_t)i * n + j]);
+            out[it * n * ld + i * ld + (long)p * n + j] = tmp[(size_t)i * n + j].real();
+          }
+      }
+  }
+  s->herm_ok[field] = st.real_enough();
+  int rc = dst.alloc(out.size() * sizeof(double));
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(dst.p, out.data(), out.size() * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+
 int m4q_session_upload(m4q_session* s, int32_t field, const void* host, size_t bytes) {
   if (!s || field < 0 || field >= M4Q_F_COUNT || !host) return fail(M4Q_E_BADARG, "m4q_session_upload: bad argument");
   if (bytes != s->fbytes[field]) return fail(M4Q_E_BADARG, "field %d expects %zu bytes, got %zu", field, s->fbytes[field], bytes);
   if (bytes == 0) return 0;
   HIP_TRY(hipMemcpyAsync(s->f[field].p, host, bytes, hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
-  const size_t n = s->prob.dim_x, m = s->prob.dim_u;
+  const size_t n = s->prob.dim_x, m = s->prob.dim_u, P = s->shape->np;
+  const auto* ch = static_cast<const std::complex<double>*>(host);
+  int rc = 0;
   if (field == M4Q_F_Q) { s->hQ.assign((const double*)host, (const double*)host + 2 * n * n); s->costs_dirty = true; }
   if (field == M4Q_F_QF) { s->hQf.assign((const double*)host, (const double*)host + 2 * n * n); s->costs_dirty = true; }
   if (field == M4Q_F_R) { s->hR.assign((const double*)host, (const double*)host + 2 * m * m); s->costs_dirty = true; }
-  return 0;
+  if (!s->force_complex) {
+    if (field == M4Q_F_MODELS) rc = lift_upload(s, field, ch, bytes / (16 * n * n * (1 + P)), true, (int)(1 + P), s->r_models);
+    if (field == M4Q_F_X0) rc = lift_upload(s, field, ch, bytes / (16 * n), false, 1, s->r_x0);
+    if (field == M4Q_F_X_TARG) rc = lift_upload(s, field, ch, bytes / (16 * n), false, 1, s->r_xtarg);
+    if (field == M4Q_F_Q) rc = lift_upload(s, field, ch, 1, true, 1, s->r_Q);
+    if (field == M4Q_F_QF) rc = lift_upload(s, field, ch, 1, true, 1, s->r_Qf);
+    if (field == M4Q_F_R) {
+      // R acts on the (real) controls: the real path needs Im R = 0
+      LiftStat st;
+      std::vector<double> rr(m * m);
+      for (size_t i = 0; i < m * m; ++i) { st.see(ch[i]); rr[i] = ch[i].real(); }
+      s->herm_ok[field] = st.real_enough();
+      rc = s->r_R.alloc(rr.size() * 8);
+      if (!rc) HIP_TRY(hipMemcpy(s->r_R.p, rr.data(), rr.size() * 8, hipMemcpyHostToDevice));
+    }
+  }
+  return rc;
+}
+
+int m4q_session_path(const m4q_session* s) {
+  if (!s) return fail(M4Q_E_BADARG, "m4q_session_path: null session");
+  // the line-search weights are derived from Q, Qf, R at the first run; before that, answer from the uploads alone
+  const bool diag_known = !s->costs_dirty;
+  return (s->use_real() || (!diag_known && !s->force_complex && s->herm_ok[M4Q_F_MODELS] && s->herm_ok[M4Q_F_X0] &&
+                            s->herm_ok[M4Q_F_X_TARG] && s->herm_ok[M4Q_F_Q] && s->herm_ok[M4Q_F_QF] && s->herm_ok[M4Q_F_R]))
+             ? 1 : 0;
 }
 
 int m4q_session_download(m4q_session* s, int32_t field, void* host, size_t bytes) {
@@ -334,25 +463,29 @@ int m4q_session_run(m4q_session* s, int32_t step_begin, int32_t step_end) {
   const m4q_problem& p = s->prob;
   const size_t n = p.dim_x, m = p.dim_u, P = s->shape->np;
   const size_t k = p.plant_kind == M4Q_PLANT_GENERATOR ? n : (size_t)s->shape->d;
+  const bool real_path = s->use_real();
   m4q::MpcArgs a{};
   a.B = s->B; a.T = p.horizon; a.n_steps = p.n_steps; a.max_iter = p.max_iter; a.warm_start = p.warm_start;
   a.flags = p.qp_flags; a.step_begin = step_begin; a.step_end = step_end;
   a.dt = p.dt; a.sat = p.sat; a.du = p.du; a.ls_tol = p.ls_tol;
-  a.models = (const cplx*)s->f[M4Q_F_MODELS].p; a.model_stride = p.model_per_instance ? (long)(n * n * (1 + P)) : 0;
-  a.x0 = (const cplx*)s->f[M4Q_F_X0].p;
-  a.x_targ = (const cplx*)s->f[M4Q_F_X_TARG].p; a.xt_stride = p.target_per_instance ? (long)(p.target_cols * n) : 0;
+  a.models = real_path ? s->r_models.p : s->f[M4Q_F_MODELS].p; a.model_stride = p.model_per_instance ? (long)(n * n * (1 + P)) : 0;
+  a.x0c = (const cplx*)s->f[M4Q_F_X0].p;
+  a.x0s = real_path ? s->r_x0.p : s->f[M4Q_F_X0].p;
+  a.x_targ = real_path ? s->r_xtarg.p : s->f[M4Q_F_X_TARG].p; a.xt_stride = p.target_per_instance ? (long)(p.target_cols * n) : 0;
   a.u_targ = (const double*)s->f[M4Q_F_U_TARG].p; a.ut_stride = p.target_per_instance ? (long)(p.target_cols * m) : 0;
-  a.Q = (const cplx*)s->f[M4Q_F_Q].p; a.Qf = (const cplx*)s->f[M4Q_F_QF].p; a.R = (const cplx*)s->f[M4Q_F_R].p;
+  a.Q = real_path ? s->r_Q.p : s->f[M4Q_F_Q].p;
+  a.Qf = real_path ? s->r_Qf.p : s->f[M4Q_F_QF].p;
+  a.R = real_path ? s->r_R.p : s->f[M4Q_F_R].p;
   a.Cq = (const double*)s->Cq.p; a.Cqf = (const double*)s->Cqf.p; a.Cr = (const double*)s->Cr.p;
   a.Wls = s->ls_diag ? (const double*)s->Wls.p : nullptr;
   a.op0 = (const cplx*)s->f[M4Q_F_OP0].p; a.op0_stride = p.plant_per_instance ? (long)(k * k) : 0;
   a.ops = (const cplx*)s->f[M4Q_F_OPS].p; a.ops_stride = p.plant_per_instance ? (long)(m * k * k) : 0;
-  if (p.plant_kind == M4Q_PLANT_NONE) { a.op0 = a.Q; a.ops = a.Q; a.op0_stride = a.ops_stride = 0; }
+  if (p.plant_kind == M4Q_PLANT_NONE) { a.op0 = (const cplx*)s->f[M4Q_F_Q].p; a.ops = a.op0; a.op0_stride = a.ops_stride = 0; }
   a.xs = (cplx*)s->f[M4Q_F_XS].p; a.us = (double*)s->f[M4Q_F_US].p;
   a.codes = (int*)s->f[M4Q_F_CODES].p; a.steps_done = (int*)s->f[M4Q_F_STEPS_DONE].p; a.qp_solves = (int*)s->f[M4Q_F_QP_SOLVES].p;
   a.Xg = (cplx*)s->f[M4Q_F_X_GUESS].p; a.Ug = (double*)s->f[M4Q_F_U_GUESS].p;
-  a.ws_Xg = (cplx*)s->wsXg.p; a.ws_Ug = (double*)s->wsUg.p;
-  a.ws_Xo = (cplx*)s->wsXo.p; a.ws_Uo = (double*)s->wsUo.p; a.ws_gains = (cplx*)s->wsG.p;
+  a.ws_Xg = s->wsXg.p; a.ws_Ug = (double*)s->wsUg.p;
+  a.ws_Xo = s->wsXo.p; a.ws_Uo = (double*)s->wsUo.p; a.ws_gains = s->wsG.p;
   a.queue = (int*)s->queue.p;
   HIP_TRY(hipMemsetAsync(s->queue.p, 0, 64, s->stream));
   if (step_begin == 0) {
@@ -364,7 +497,7 @@ int m4q_session_run(m4q_session* s, int32_t step_begin, int32_t step_end) {
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));
   HIP_TRY(hipEventRecord(e0, s->stream));
-  rc = s->shape->launch_mpc(a, p.plant_kind, s->grid, s->stream);
+  rc = s->shape->launch_mpc(a, p.plant_kind, real_path ? 1 : 0, s->grid, s->stream);
   if (rc) return fail(rc, "mpc kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));
   HIP_TRY(hipEventRecord(e1, s->stream));
   s->pending.emplace_back(e0, e1);
@@ -410,7 +543,7 @@ int m4q_session_info(const m4q_session* s, int64_t* hbm_bytes, int32_t* grid, in
   tot += (int64_t)(s->wsXg.bytes + s->wsUg.bytes + s->wsXo.bytes + s->wsUo.bytes + s->wsG.bytes);
   if (hbm_bytes) *hbm_bytes = tot;
   if (grid) *grid = s->grid;
-  if (lds_bytes) *lds_bytes = (int32_t)s->shape->mpc_lds_bytes();
+  if (lds_bytes) *lds_bytes = (int32_t)s->shape->mpc_lds_bytes(s->use_real() ? 1 : 0);
   return 0;
 }
 

@@ -101,11 +101,14 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // ---- row broadcast: every lane of a 16-lane DPP row reads lane K of its own row ----
 // DP-ALU DPP (gfx90a+) supports exactly one control for 64-bit operands: row_newbcast:K.  It is
-// available on v_fmac_f64 (VOP2) and v_mov_b64 (VOP1), so the broadcast
-// is folded INTO the FMA: acc += lane_K(a) * b is one instruction and no temporary exists.
-// A VALU write of a VGPR needs 2 wait states before a DPP read of it and hipcc pads nothing inside
-// an asm string (cdna_hip_programming.md 5.7 item 2): every block opens with s_nop 1; inside a
-// block no instruction DPP-reads a register written by the block.
+// available on v_fmac_f64 (VOP2) and v_mov_b64 (VOP1), so the broadcast is folded INTO the FMA:
+// acc += lane_K(a) * b is one instruction and no temporary exists.  Measured on MI355X
+// (tools/ubench_dpp.hip): v_fmac_f64_dpp issues at the plain v_fma_f64 rate (4.1-4.3 cycles per
+// wave-instruction per SIMD, 78 TFLOP/s chip-wide); an unfused v_mov_b64_dpp + FMA pair runs at 0.66x.
+// v_add/max/mul_f64 have no VOP2 encoding on gfx9, hence no DPP form.
+// A VALU write of a VGPR needs 2 wait states before a DPP read of it and hipcc pads nothing inside an
+// asm string (cdna_hip_programming.md 5.7 item 2): every asm statement opens with `s_nop 1`; the
+// multi-term statements of m4q_dpp_gen.h pay it once per 8-16 FMAs.
 #define M4Q_DPP " row_mask:0xf bank_mask:0xf\n\t"
 
 #ifndef M4Q_BCAST_SHFL
@@ -115,76 +118,178 @@ __device__ __forceinline__ double bcast(double x) {
   asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2" M4Q_DPP : "=v"(r) : "v"(x), "n"(K));
   return r;
 }
-// acc += lane_K(a) * b
-template <int K>
-__device__ __forceinline__ void fmac_bc(double& acc, double a, double b) {
-  asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3" M4Q_DPP : "+v"(acc) : "v"(a), "v"(b), "n"(K));
-}
-// acc += lane_K(a).  v_add_f64 / v_max_f64 have no VOP2 encoding on gfx9, hence no DPP form: the add is an
-// FMA with a unit multiplier, the max goes through v_mov_b64_dpp.
-template <int K>
-__device__ __forceinline__ void add_bc(double& acc, double a) {
-  fmac_bc<K>(acc, a, 1.0);
-}
-template <int K>
-__device__ __forceinline__ void max_bc(double& acc, double a) {
-  acc = fmax(acc, bcast<K>(a));
-}
-// acc += lane_K(a) * b            (complex; SA/SB/SC/SD are the signs of the four products)
-//   re += a.re b.re ; im += a.re b.im ; re += SC a.im b.im ; im += SD a.im b.re
-#define M4Q_CMAC_ASM(SC, SD)                                                                             \
-  asm("s_nop 1\n\t"                                                                                      \
-      "v_fmac_f64_dpp %0, %2, %4 row_newbcast:%6" M4Q_DPP "v_fmac_f64_dpp %1, %2, %5 row_newbcast:%6" M4Q_DPP \
-      "v_fmac_f64_dpp %0, " SC "%3, %5 row_newbcast:%6" M4Q_DPP "v_fmac_f64_dpp %1, " SD "%3, %4 row_newbcast:%6" M4Q_DPP \
-      : "+v"(acc.re), "+v"(acc.im)                                                                       \
-      : "v"(a.re), "v"(a.im), "v"(b.re), "v"(b.im), "n"(K))
-template <int K>
-__device__ __forceinline__ void cmac_bc(cplx& acc, cplx a, cplx b) {          // acc += lane_K(a) * b
-  M4Q_CMAC_ASM("-", "");
-}
-template <int K>
-__device__ __forceinline__ void cmac_cjbc(cplx& acc, cplx a, cplx b) {        // acc += conj(lane_K(a)) * b
-  M4Q_CMAC_ASM("", "-");
-}
-// acc += lane_K(a) * conj(b):  re += a.re b.re + a.im b.im ; im += -a.re b.im + a.im b.re
-template <int K>
-__device__ __forceinline__ void cmac_bc_cjown(cplx& acc, cplx a, cplx b) {
-  asm("s_nop 1\n\t"
-      "v_fmac_f64_dpp %0, %2, %4 row_newbcast:%6" M4Q_DPP "v_fmac_f64_dpp %1, -%2, %5 row_newbcast:%6" M4Q_DPP
-      "v_fmac_f64_dpp %0, %3, %5 row_newbcast:%6" M4Q_DPP "v_fmac_f64_dpp %1, %3, %4 row_newbcast:%6" M4Q_DPP
-      : "+v"(acc.re), "+v"(acc.im)
-      : "v"(a.re), "v"(a.im), "v"(b.re), "v"(b.im), "n"(K));
-}
 #else
-// reference implementation of the same primitives through ds_bpermute (debug / A-B builds)
 template <int K>
 __device__ __forceinline__ double bcast(double x) { return __shfl(x, K, 16); }
-template <int K>
-__device__ __forceinline__ void fmac_bc(double& acc, double a, double b) { acc = fma(bcast<K>(a), b, acc); }
-template <int K>
-__device__ __forceinline__ void add_bc(double& acc, double a) { acc += bcast<K>(a); }
-template <int K>
-__device__ __forceinline__ void max_bc(double& acc, double a) { acc = fmax(acc, bcast<K>(a)); }
-template <int K>
-__device__ __forceinline__ void cmac_bc(cplx& acc, cplx a, cplx b) { cmac(acc, mk(bcast<K>(a.re), bcast<K>(a.im)), b); }
-template <int K>
-__device__ __forceinline__ void cmac_cjbc(cplx& acc, cplx a, cplx b) { cmac_cj(acc, mk(bcast<K>(a.re), bcast<K>(a.im)), b); }
-template <int K>
-__device__ __forceinline__ void cmac_bc_cjown(cplx& acc, cplx a, cplx b) {
-  cmac(acc, mk(bcast<K>(a.re), bcast<K>(a.im)), cconj(b));
-}
 #endif
 template <int K>
 __device__ __forceinline__ cplx bcast(cplx x) {
   return mk(bcast<K>(x.re), bcast<K>(x.im));
 }
 
-// Sum / max over lanes 0..N-1 of the row; result replicated in every lane of the row.
+}  // namespace m4q
+#include "m4q_dpp_gen.h"
+namespace m4q {
+
+// ---- scalar-generic layer: the same algorithms run on S = cplx (any model) and S = double (models that
+// preserve Hermiticity, expressed in a Hermitian operator basis where everything is real) ----
+__device__ __forceinline__ double cadd(double a, double b) { return a + b; }
+__device__ __forceinline__ double csub(double a, double b) { return a - b; }
+__device__ __forceinline__ double cneg(double a) { return -a; }
+__device__ __forceinline__ double cconj(double a) { return a; }
+__device__ __forceinline__ double cscale(double a, double s) { return a * s; }
+__device__ __forceinline__ double cmul(double a, double b) { return a * b; }
+__device__ __forceinline__ void cmac(double& acc, double a, double b) { acc = fma(a, b, acc); }
+__device__ __forceinline__ void cmac_cj(double& acc, double a, double b) { acc = fma(a, b, acc); }
+__device__ __forceinline__ void cmac_r(double& acc, double a, double s) { acc = fma(a, s, acc); }
+__device__ __forceinline__ double csel(bool c, double a, double b) { return c ? a : b; }
+__device__ __forceinline__ double real_of(double a) { return a; }
+__device__ __forceinline__ double real_of(cplx a) { return a.re; }
+__device__ __forceinline__ double norm2(double a) { return a * a; }
+__device__ __forceinline__ double norm2(cplx a) { return fma(a.re, a.re, a.im * a.im); }
+// Re(conj(a) b)
+__device__ __forceinline__ double dot_re(double a, double b) { return a * b; }
+__device__ __forceinline__ double dot_re(cplx a, cplx b) { return fma(a.re, b.re, a.im * b.im); }
+template <class S> __device__ __forceinline__ S zero_of();
+template <> __device__ __forceinline__ double zero_of<double>() { return 0.0; }
+template <> __device__ __forceinline__ cplx zero_of<cplx>() { return czero(); }
+__device__ __forceinline__ cplx as_cplx(cplx a) { return a; }
+__device__ __forceinline__ cplx as_cplx(double a) { return mk(a, 0.0); }
+template <class S> __device__ __forceinline__ S from_cplx(cplx a);
+template <> __device__ __forceinline__ cplx from_cplx<cplx>(cplx a) { return a; }
+template <> __device__ __forceinline__ double from_cplx<double>(cplx a) { return a.re; }
+template <class S> __device__ __forceinline__ S from_real(double r);
+template <> __device__ __forceinline__ double from_real<double>(double r) { return r; }
+template <> __device__ __forceinline__ cplx from_real<cplx>(double r) { return mk(r, 0.0); }
+
+// N-term statements, uniform over S (the conjugation flags are meaningless for double)
+template <bool CA, bool CB, int K0>
+__device__ __forceinline__ void macN(double& c0, double a0, double b0) { fmacN<K0>(c0, a0, b0); }
+template <bool CA, bool CB, int K0, int K1>
+__device__ __forceinline__ void macN(double& c0, double a0, double b0, double& c1, double a1, double b1) {
+  fmacN<K0, K1>(c0, a0, b0, c1, a1, b1);
+}
+template <bool CA, bool CB, int K0, int K1, int K2>
+__device__ __forceinline__ void macN(double& c0, double a0, double b0, double& c1, double a1, double b1, double& c2, double a2,
+                                     double b2) {
+  fmacN<K0, K1, K2>(c0, a0, b0, c1, a1, b1, c2, a2, b2);
+}
+template <bool CA, bool CB, int K0, int K1, int K2, int K3>
+__device__ __forceinline__ void macN(double& c0, double a0, double b0, double& c1, double a1, double b1, double& c2, double a2,
+                                     double b2, double& c3, double a3, double b3) {
+  fmacN<K0, K1, K2, K3>(c0, a0, b0, c1, a1, b1, c2, a2, b2, c3, a3, b3);
+}
+template <bool CA, bool CB, int K0>
+__device__ __forceinline__ void macN(cplx& c0, cplx a0, cplx b0) { cmacN<CA, CB, K0>(c0, a0, b0); }
+template <bool CA, bool CB, int K0, int K1>
+__device__ __forceinline__ void macN(cplx& c0, cplx a0, cplx b0, cplx& c1, cplx a1, cplx b1) {
+  cmacN<CA, CB, K0, K1>(c0, a0, b0, c1, a1, b1);
+}
+template <bool CA, bool CB, int K0, int K1, int K2>
+__device__ __forceinline__ void macN(cplx& c0, cplx a0, cplx b0, cplx& c1, cplx a1, cplx b1, cplx& c2, cplx a2, cplx b2) {
+  cmacN<CA, CB, K0, K1, K2>(c0, a0, b0, c1, a1, b1, c2, a2, b2);
+}
+template <bool CA, bool CB, int K0, int K1, int K2, int K3>
+__device__ __forceinline__ void macN(cplx& c0, cplx a0, cplx b0, cplx& c1, cplx a1, cplx b1, cplx& c2, cplx a2, cplx b2,
+                                     cplx& c3, cplx a3, cplx b3) {
+  cmacN<CA, CB, K0, K1, K2, K3>(c0, a0, b0, c1, a1, b1, c2, a2, b2, c3, a3, b3);
+}
+
+// single-term conveniences
+template <int K, class S>
+__device__ __forceinline__ void cmac_bc(S& acc, S a, S b) { macN<false, false, K>(acc, a, b); }       // acc += lane_K(a) * b
+template <int K, class S>
+__device__ __forceinline__ void cmac_cjbc(S& acc, S a, S b) { macN<true, false, K>(acc, a, b); }      // acc += conj(lane_K(a)) * b
+template <int K>
+__device__ __forceinline__ void fmac_bc(double& acc, double a, double b) { fmacN<K>(acc, a, b); }
+
+// acc[i] += opA(lane_K(a[i])) * opB(b)   for i in [I0, N): same lane, a chunk of up to four per statement
+template <bool CA, bool CB, int K, int I0, int N, class S>
+__device__ __forceinline__ void mac_same_lane(S (&acc)[N], const S (&a)[N], S b) {
+  if constexpr (N - I0 >= 4) {
+    macN<CA, CB, K, K, K, K>(acc[I0], a[I0], b, acc[I0 + 1], a[I0 + 1], b, acc[I0 + 2], a[I0 + 2], b, acc[I0 + 3], a[I0 + 3], b);
+    mac_same_lane<CA, CB, K, I0 + 4, N>(acc, a, b);
+  } else if constexpr (N - I0 == 3) {
+    macN<CA, CB, K, K, K>(acc[I0], a[I0], b, acc[I0 + 1], a[I0 + 1], b, acc[I0 + 2], a[I0 + 2], b);
+  } else if constexpr (N - I0 == 2) {
+    macN<CA, CB, K, K>(acc[I0], a[I0], b, acc[I0 + 1], a[I0 + 1], b);
+  } else if constexpr (N - I0 == 1) {
+    macN<CA, CB, K>(acc[I0], a[I0], b);
+  }
+}
+// acc[i] += opA(lane_K(a)) * opB(b[i])   same lane, same broadcast source, per-term own operand
+template <bool CA, bool CB, int K, int I0, int N, class S>
+__device__ __forceinline__ void mac_same_src(S (&acc)[N], S a, const S (&b)[N]) {
+  if constexpr (N - I0 >= 4) {
+    macN<CA, CB, K, K, K, K>(acc[I0], a, b[I0], acc[I0 + 1], a, b[I0 + 1], acc[I0 + 2], a, b[I0 + 2], acc[I0 + 3], a, b[I0 + 3]);
+    mac_same_src<CA, CB, K, I0 + 4, N>(acc, a, b);
+  } else if constexpr (N - I0 == 3) {
+    macN<CA, CB, K, K, K>(acc[I0], a, b[I0], acc[I0 + 1], a, b[I0 + 1], acc[I0 + 2], a, b[I0 + 2]);
+  } else if constexpr (N - I0 == 2) {
+    macN<CA, CB, K, K>(acc[I0], a, b[I0], acc[I0 + 1], a, b[I0 + 1]);
+  } else if constexpr (N - I0 == 1) {
+    macN<CA, CB, K>(acc[I0], a, b[I0]);
+  }
+}
+// acc[i] += opA(lane_i(a)) * opB(b)   for i in [I0, N): the broadcast lane is the row index
+template <bool CA, bool CB, int I0, int N, class S>
+__device__ __forceinline__ void mac_lane_index(S (&acc)[N], S a, S b) {
+  if constexpr (N - I0 >= 4) {
+    macN<CA, CB, I0, I0 + 1, I0 + 2, I0 + 3>(acc[I0], a, b, acc[I0 + 1], a, b, acc[I0 + 2], a, b, acc[I0 + 3], a, b);
+    mac_lane_index<CA, CB, I0 + 4, N>(acc, a, b);
+  } else if constexpr (N - I0 == 3) {
+    macN<CA, CB, I0, I0 + 1, I0 + 2>(acc[I0], a, b, acc[I0 + 1], a, b, acc[I0 + 2], a, b);
+  } else if constexpr (N - I0 == 2) {
+    macN<CA, CB, I0, I0 + 1>(acc[I0], a, b, acc[I0 + 1], a, b);
+  } else if constexpr (N - I0 == 1) {
+    macN<CA, CB, I0>(acc[I0], a, b);
+  }
+}
+// part[c] += opA(lane_i(v)) * opB(m[i]) over i in [I0, N), four running partial sums
+template <bool CA, bool CB, int I0, int N, class S>
+__device__ __forceinline__ void dot_lane_index_acc(S (&part)[4], S v, const S (&m)[N]) {
+  if constexpr (N - I0 >= 4) {
+    macN<CA, CB, I0, I0 + 1, I0 + 2, I0 + 3>(part[0], v, m[I0], part[1], v, m[I0 + 1], part[2], v, m[I0 + 2], part[3], v, m[I0 + 3]);
+    dot_lane_index_acc<CA, CB, I0 + 4, N>(part, v, m);
+  } else if constexpr (N - I0 == 3) {
+    macN<CA, CB, I0, I0 + 1, I0 + 2>(part[0], v, m[I0], part[1], v, m[I0 + 1], part[2], v, m[I0 + 2]);
+  } else if constexpr (N - I0 == 2) {
+    macN<CA, CB, I0, I0 + 1>(part[0], v, m[I0], part[1], v, m[I0 + 1]);
+  } else if constexpr (N - I0 == 1) {
+    macN<CA, CB, I0>(part[0], v, m[I0]);
+  }
+}
+// sum_i opA(lane_i(v)) * opB(m[i])
+template <bool CA, bool CB, int N, class S>
+__device__ __forceinline__ S dot_lane_index(S v, const S (&m)[N]) {
+  S part[4] = {zero_of<S>(), zero_of<S>(), zero_of<S>(), zero_of<S>()};
+  dot_lane_index_acc<CA, CB, 0, N>(part, v, m);
+  return cadd(cadd(part[0], part[1]), cadd(part[2], part[3]));
+}
+
+// Sum over lanes 0..N-1 of the row; result replicated in every lane of the row.
+template <int I0, int N>
+__device__ __forceinline__ void rowsum_acc(double (&p)[8], double v, double one) {
+  if constexpr (N - I0 >= 8) {
+    fmacN<I0, I0 + 1, I0 + 2, I0 + 3, I0 + 4, I0 + 5, I0 + 6, I0 + 7>(p[0], v, one, p[1], v, one, p[2], v, one, p[3], v, one, p[4],
+                                                                      v, one, p[5], v, one, p[6], v, one, p[7], v, one);
+    rowsum_acc<I0 + 8, N>(p, v, one);
+  } else if constexpr (N - I0 >= 4) {
+    fmacN<I0, I0 + 1, I0 + 2, I0 + 3>(p[0], v, one, p[1], v, one, p[2], v, one, p[3], v, one);
+    rowsum_acc<I0 + 4, N>(p, v, one);
+  } else if constexpr (N - I0 == 3) {
+    fmacN<I0, I0 + 1, I0 + 2>(p[4], v, one, p[5], v, one, p[6], v, one);
+  } else if constexpr (N - I0 == 2) {
+    fmacN<I0, I0 + 1>(p[4], v, one, p[5], v, one);
+  } else if constexpr (N - I0 == 1) {
+    fmacN<I0>(p[4], v, one);
+  }
+}
 template <int N>
 __device__ __forceinline__ double rowsum(double v) {
-  double s = 0.0;
-  static_for<0, N>([&](auto k) { add_bc<decltype(k)::value>(s, v); });
-  return s;
+  double p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  rowsum_acc<0, N>(p, v, 1.0);
+  return ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
 }
 template <int N>
 __device__ __forceinline__ cplx rowsum(cplx v) {
@@ -193,43 +298,37 @@ __device__ __forceinline__ cplx rowsum(cplx v) {
 template <int N>
 __device__ __forceinline__ double rowmax(double v) {
   double s = bcast<0>(v);
-  static_for<1, N>([&](auto k) { max_bc<decltype(k)::value>(s, v); });
+  static_for<1, N>([&](auto k) { s = fmax(s, bcast<decltype(k)::value>(v)); });
   return s;
 }
 
 // C[:, j] = M * B[:, j]   with M, B column-owned (N x N):  C[i] += lane_k(M[i]) * B[k]
-template <int N>
-__device__ __forceinline__ void matmul_cols(cplx (&C)[N], const cplx (&M)[N], const cplx (&Bc)[N]) {
+template <int N, class S>
+__device__ __forceinline__ void matmul_cols(S (&C)[N], const S (&M)[N], const S (&Bc)[N]) {
 #pragma unroll
-  for (int i = 0; i < N; ++i) C[i] = czero();
+  for (int i = 0; i < N; ++i) C[i] = zero_of<S>();
   static_for<0, N>([&](auto kk) {
     constexpr int k = decltype(kk)::value;
-#pragma unroll
-    for (int i = 0; i < N; ++i) cmac_bc<k>(C[i], M[i], Bc[k]);
+    mac_same_lane<false, false, k, 0, N>(C, M, Bc[k]);
   });
 }
 
 // C[:, j] += M^H * B[:, j]   with M, B column-owned:  C[i] += conj(lane_i(M[k])) * B[k]
-template <int N>
-__device__ __forceinline__ void matmul_cols_hn_acc(cplx (&C)[N], const cplx (&M)[N], const cplx (&Bc)[N]) {
+template <int N, class S>
+__device__ __forceinline__ void matmul_cols_hn_acc(S (&C)[N], const S (&M)[N], const S (&Bc)[N]) {
 #pragma unroll
-  for (int k = 0; k < N; ++k) {
-    static_for<0, N>([&](auto ii) {
-      constexpr int i = decltype(ii)::value;
-      cmac_cjbc<i>(C[i], M[k], Bc[k]);
-    });
-  }
+  for (int k = 0; k < N; ++k) mac_lane_index<true, false, 0, N>(C, M[k], Bc[k]);
 }
 
 // y_j = sum_i conj(M[i][j]) v_i  with M column-owned, v distributed  (= (M^H v)_j; = (M v)_j if M Hermitian)
-template <int N>
-__device__ __forceinline__ cplx matvec_h(const cplx (&M)[N], cplx v) {
-  cplx y = czero();
-  static_for<0, N>([&](auto ii) {
-    constexpr int i = decltype(ii)::value;
-    cmac_bc_cjown<i>(y, v, M[i]);
-  });
-  return y;
+template <int N, class S>
+__device__ __forceinline__ S matvec_h(const S (&M)[N], S v) {
+  return dot_lane_index<false, true, N>(v, M);
+}
+// y_j = sum_i M[i][j] v_i  = (M^T v)_j
+template <int N, class S>
+__device__ __forceinline__ S matvec_t(const S (&M)[N], S v) {
+  return dot_lane_index<false, false, N>(v, M);
 }
 
 __device__ __forceinline__ bool finite_d(double x) { return __builtin_isfinite(x); }

@@ -24,8 +24,8 @@ constexpr int DD = (NX == 4) ? 2 : (NX == 9) ? 3 : 4;
 static_assert(DD * DD == NX, "dim_x must be 4, 9 or 16");
 constexpr int NP = PowTab<NU, ORDER>::NP;
 constexpr int PITCH = ModelPitch<NX>::value;
-constexpr int MODEL_ELEMS = (1 + NP) * NX * PITCH;        // per instance, complex elements in LDS
-constexpr int SCRATCH_ELEMS = DD * DD + 2 * NX;           // plant scratch per instance
+constexpr int MODEL_ELEMS = (1 + NP) * NX * PITCH;        // per instance, elements (of S) in LDS
+constexpr int SCRATCH_ELEMS = DD * DD + 2 * NX;           // plant / basis-change scratch per instance (complex)
 constexpr int ROWS = 4;                                    // instances per wavefront
 
 // register budget: waves per SIMD the kernels are compiled for (512 / budget VGPRs per lane)
@@ -37,14 +37,15 @@ constexpr int ROWS = 4;                                    // instances per wave
 extern __shared__ __align__(16) unsigned char m4q_lds_raw[];
 
 // copy one instance's model (DMDc.A layout, n x n(1+P) row-major) into its LDS block [1+P][n][PITCH]
-__device__ __forceinline__ void stage_model(cplx* dst, const GView& src, int jj) {
+template <class S>
+__device__ __forceinline__ void stage_model(S* dst, const S* src, int jj) {
   constexpr int W = NX * (1 + NP);
   for (int e = jj; e < NX * W; e += 16) {
     const int i = e / W;
     const int pk = e - i * W;
     const int p = pk / NX;
     const int k = pk - p * NX;
-    dst[(p * NX + i) * PITCH + k] = src.ld<cplx>(e);
+    dst[(p * NX + i) * PITCH + k] = src[e];
   }
 }
 
@@ -69,52 +70,69 @@ struct LaneGeo {
 // loop performs one QP solve for each row at whatever point of its run that row has reached.  SQP
 // iteration counts at steps 0-1 range from 14 to 100 (config 3): with rows in lockstep a quad runs at
 // the pace of its slowest member and a static split leaves the slowest wave 1.6x the mean.
+//
+// S = cplx: any model.  S = double: Hermiticity-preserving models in the Hermitian operator basis
+// (a quarter of the FMAs, half the LDS and workspace traffic); the host decides (m4q_capi.hip).
 // ---------------------------------------------------------------------------------------------
 constexpr int COST_ELEMS = 2 * NX * NX + NU * NU;         // Q, Qf, R staged in LDS once per workgroup
 constexpr int WLS_DOUBLES = 4 * NX + 2 * NU;               // diagonal line-search weights, staged after them
 
+template <class S>
+constexpr size_t mpc_lds_layout_bytes() {
+  return sizeof(S) * (size_t)(ROWS * MODEL_ELEMS + COST_ELEMS) + sizeof(cplx) * (size_t)(ROWS * SCRATCH_ELEMS) +
+         sizeof(double) * (size_t)(WLS_DOUBLES + 2);
+}
+
 __device__ __forceinline__ int row_bcast_int(int v) { return __shfl(v, 0, 16); }
 
-template <int PLANT>
+template <class S, int PLANT>
 __global__ __launch_bounds__(64) M4Q_OCC void mpc_kernel(MpcArgs a) {
-  cplx* lds = reinterpret_cast<cplx*>(m4q_lds_raw);
+  // LDS: [4 x scratch (complex)] [4 x model (S)] [Q Qf R (S)] [line-search weights]
+  cplx* scratch = reinterpret_cast<cplx*>(m4q_lds_raw);
+  S* lds = reinterpret_cast<S*>(scratch + ROWS * SCRATCH_ELEMS);
   const LaneGeo L;
   const int g = L.g, jj = L.jj, j = L.j;
   const bool lane_ok = L.lane_ok;
   const int T = a.T;
-  cplx* mdl = lds + g * MODEL_ELEMS;
-  cplx* scratch = lds + ROWS * MODEL_ELEMS + g * SCRATCH_ELEMS;
-  cplx* ldsQ = lds + ROWS * (MODEL_ELEMS + SCRATCH_ELEMS);
-  for (int e = threadIdx.x; e < COST_ELEMS; e += 64)
-    ldsQ[e] = e < NX * NX ? a.Q[e] : (e < 2 * NX * NX ? a.Qf[e - NX * NX] : a.R[e - 2 * NX * NX]);
+  S* mdl = lds + g * MODEL_ELEMS;
+  scratch += g * SCRATCH_ELEMS;
+  S* ldsQ = lds + ROWS * MODEL_ELEMS;
+  {
+    const S* gQ = static_cast<const S*>(a.Q);
+    const S* gQf = static_cast<const S*>(a.Qf);
+    const S* gR = static_cast<const S*>(a.R);
+    for (int e = threadIdx.x; e < COST_ELEMS; e += 64)
+      ldsQ[e] = e < NX * NX ? gQ[e] : (e < 2 * NX * NX ? gQf[e - NX * NX] : gR[e - 2 * NX * NX]);
+  }
   double* ldsW = reinterpret_cast<double*>(ldsQ + COST_ELEMS);
   const bool ls_diag = a.Wls != nullptr;
   if (ls_diag) {
     for (int e = threadIdx.x; e < WLS_DOUBLES; e += 64) ldsW[e] = a.Wls[e];
   }
-  CostRef cost;
+  CostRef<S> cost;
   cost.Q = ldsQ; cost.Qf = ldsQ + NX * NX; cost.q_stride = 0; cost.R = ldsQ + 2 * NX * NX; cost.r_stride = 0;
   // workspace of this resident row: wave-uniform base per workgroup, lane part = row within the wave
   const unsigned sX = (unsigned)(T + 1) * NX, sU = (unsigned)T * NU, sG = (unsigned)T * (NX + 1) * NU;
-  const GView Xg = gview(a.ws_Xg, (long)blockIdx.x * ROWS * sX, g * sX);
+  const GView Xg = gview(static_cast<S*>(a.ws_Xg), (long)blockIdx.x * ROWS * sX, g * sX);
   const GView Ug = gview(a.ws_Ug, (long)blockIdx.x * ROWS * sU, g * sU);
-  const GView Xo = gview(a.ws_Xo, (long)blockIdx.x * ROWS * sX, g * sX);
+  const GView Xo = gview(static_cast<S*>(a.ws_Xo), (long)blockIdx.x * ROWS * sX, g * sX);
   const GView Uo = gview(a.ws_Uo, (long)blockIdx.x * ROWS * sU, g * sU);
-  const GView gains = gview(a.ws_gains, (long)blockIdx.x * ROWS * sG, g * sG);
-  FusedProv<NX, NU, ORDER> prov;
+  const GView gains = gview(static_cast<S*>(a.ws_gains), (long)blockIdx.x * ROWS * sG, g * sG);
+  FusedProv<S, NX, NU, ORDER> prov;
   prov.mdl = mdl; prov.Xg = Xg; prov.Ug = Ug; prov.j = j;
   const long sXs = (long)(a.n_steps + 1) * NX, sUs = (long)a.n_steps * NU;
   const bool band = (a.flags & QP_DU_BAND) != 0;
+  const S* x_targ = static_cast<const S*>(a.x_targ);
 
   // per-row state (uniform inside a row)
   long b = 0;
   bool active = false, need_new = true;
   int step = 0, iter = 0, code = 0, done_steps = 0;
-  cplx x_cur = czero();
+  S x_cur = zero_of<S>();
   double uprev[NU];
 #pragma unroll
   for (int k = 0; k < NU; ++k) uprev[k] = 0.0;
-  GView xt = gview(a.x_targ, 0, 0), ut = gview(a.u_targ, 0, 0), op0 = gview(a.op0, 0, 0), ops = gview(a.ops, 0, 0);
+  GView xt = gview(x_targ, 0, 0), ut = gview(a.u_targ, 0, 0), op0 = gview(a.op0, 0, 0), ops = gview(a.ops, 0, 0);
   __syncthreads();
 
   while (true) {
@@ -128,31 +146,40 @@ __global__ __launch_bounds__(64) M4Q_OCC void mpc_kernel(MpcArgs a) {
       if (fresh) b = nb;
       __syncthreads();
       if (fresh) {
-        stage_model(mdl, gview(a.models + b * a.model_stride, 0, 0), jj);
-        xt = gview(a.x_targ, 0, (unsigned)(b * a.xt_stride));
+        stage_model(mdl, static_cast<const S*>(a.models) + b * a.model_stride, jj);
+        xt = gview(x_targ, 0, (unsigned)(b * a.xt_stride));
         ut = gview(a.u_targ, 0, (unsigned)(b * a.ut_stride));
         op0 = gview(a.op0, 0, (unsigned)(b * a.op0_stride));
         ops = gview(a.ops, 0, (unsigned)(b * a.ops_stride));
         step = a.step_begin;
         iter = 0;
-        if (a.step_begin == 0) {
+        code = 0;
+        done_steps = 0;
+      }
+      if (a.step_begin == 0) {
+        if (fresh) {
           // X_guess = tile(x0), U_guess = 0 (mpc.py:141-142); xs[0] = x0 (:160)
-          const cplx x0 = a.x0[b * NX + j];
+          const S x0 = static_cast<const S*>(a.x0s)[b * NX + j];
           x_cur = x0;
           if (lane_ok) {
-            for (int t = 0; t <= T; ++t) Xg.st<cplx>(t * NX + j, x0);
-            a.xs[b * sXs + j] = x0;
+            for (int t = 0; t <= T; ++t) Xg.st<S>(t * NX + j, x0);
+            a.xs[b * sXs + j] = a.x0c[b * NX + j];
           }
           for (int e = jj; e < T * NU; e += 16) Ug.st<double>(e, 0.0);
-          code = 0;
-          done_steps = 0;
-        } else {
-          // resume: the SQP guess, state and exit code of a previous launch (fields X_GUESS/U_GUESS/XS/US/CODES)
-          if (lane_ok) {
-            for (int t = 0; t <= T; ++t) Xg.st<cplx>(t * NX + j, a.Xg[b * sX + t * NX + j]);
-          }
+        }
+      } else {
+        // resume: the SQP guess, state and exit code of a previous launch (fields X_GUESS/U_GUESS/XS/US/CODES).
+        // The stored guess is complex in the original basis; the basis change needs every lane (LDS exchange).
+        for (int t = 0; t <= T; ++t) {
+          const cplx xc = fresh ? a.Xg[b * sX + t * NX + j] : czero();
+          const S r = BasisIO<S>::template to_state<NX, DD>(xc, scratch, j, jj);
+          if (fresh && lane_ok) Xg.st<S>(t * NX + j, r);
+        }
+        const cplx xc = fresh ? a.xs[b * sXs + (long)a.step_begin * NX + j] : czero();
+        const S r = BasisIO<S>::template to_state<NX, DD>(xc, scratch, j, jj);
+        if (fresh) {
+          x_cur = r;
           for (int e = jj; e < T * NU; e += 16) Ug.st<double>(e, a.Ug[b * sU + e]);
-          x_cur = a.xs[b * sXs + (long)a.step_begin * NX + j];
           code = a.codes[b];
           done_steps = a.steps_done[b];
 #pragma unroll
@@ -169,7 +196,7 @@ __global__ __launch_bounds__(64) M4Q_OCC void mpc_kernel(MpcArgs a) {
     // target window: X_ref = X_targ[:, :T+1] for steps 0 and 1, then X_targ[:, step-1:...] (mpc.py:145,276)
     const int w = step <= 1 ? 0 : step - 1;
     Window win;
-    win.xbm = xt.lane<cplx>((unsigned)w * NX);
+    win.xbm = xt.lane<S>((unsigned)w * NX);
     win.ubm = ut.lane<double>((unsigned)w * NU);
     double lo0[NU], hi0[NU];
 #pragma unroll
@@ -181,9 +208,11 @@ __global__ __launch_bounds__(64) M4Q_OCC void mpc_kernel(MpcArgs a) {
     }
     const bool use_ls = !(a.warm_start && step > 1);        // mpc.py:208-213
     const bool st = running && lane_ok;
-    riccati_backward<NX, NU>(prov, T, win, cost, a.flags, gains, j, st);
+    riccati_backward<S, NX, NU>(prov, T, win, cost, a.flags, gains, j, st);
     __syncthreads();
-    const double chk = rollout_forward<NX, NU, false>(prov, T, x_cur, win, cost, a.flags, gains, a.sat, lo0, hi0, Xo, Uo, j, st);
+    double uapp[NU];
+    const double chk = rollout_forward<S, NX, NU, false>(prov, T, x_cur, win, cost, a.flags, gains, a.sat, lo0, hi0, Xo, Uo, j, st,
+                                                         uapp);
     __syncthreads();
     const bool fail = !finite_d(chk);                      // mpc.py:200-203
     if (running) ++iter;
@@ -192,9 +221,12 @@ __global__ __launch_bounds__(64) M4Q_OCC void mpc_kernel(MpcArgs a) {
     if (__any(running && use_ls)) {
       ZView<NX, NU> z;
       z.T = T; z.Xg = Xg; z.Xo = Xo; z.Xt = win.xbm; z.Ug = Ug; z.Uo = Uo; z.Ut = win.ubm;
-      double al, stepn;
-      if (ls_diag) line_search_diag<NX, NU>(z, ldsW, ldsW + 2 * NX, ldsW + 4 * NX, jj, al, stepn);
-      else line_search<NX, NU>(z, a.Cq, a.Cqf, a.Cr, jj, al, stepn);
+      double al = 1.0, stepn = 0.0;
+      if (ls_diag) {
+        line_search_diag<S, NX, NU, DD>(z, ldsW, ldsW + 2 * NX, ldsW + 4 * NX, jj, al, stepn);
+      } else {
+        if constexpr (sizeof(S) == sizeof(cplx)) line_search<NX, NU>(z, a.Cq, a.Cqf, a.Cr, jj, al, stepn);
+      }
       if (use_ls) { alpha = al; fin = stepn < a.ls_tol; }   // mpc.py:224
     }
     __syncthreads();
@@ -202,8 +234,8 @@ __global__ __launch_bounds__(64) M4Q_OCC void mpc_kernel(MpcArgs a) {
     // X_guess += alpha (X_opt - X_guess) (mpc.py:228-229)
     if (upd && lane_ok) {
       for (int t = 0; t <= T; ++t) {
-        const cplx xg = Xg.ld<cplx>(t * NX + j), xo = Xo.ld<cplx>(t * NX + j);
-        Xg.st<cplx>(t * NX + j, mk(xg.re + alpha * (xo.re - xg.re), xg.im + alpha * (xo.im - xg.im)));
+        const S xg = Xg.ld<S>(t * NX + j), xo = Xo.ld<S>(t * NX + j);
+        Xg.st<S>(t * NX + j, cadd(xg, cscale(csub(xo, xg), alpha)));
       }
     }
     if (upd) {
@@ -221,9 +253,6 @@ __global__ __launch_bounds__(64) M4Q_OCC void mpc_kernel(MpcArgs a) {
       if (step_done && jj == 0) a.qp_solves[b * a.n_steps + step] = iter;
       const bool ok = step_done && !fail;
       // apply U_opt[:, 0] (mpc.py:250), propagate the plant (mpc.py:256-260)
-      double uapp[NU];
-#pragma unroll
-      for (int k = 0; k < NU; ++k) uapp[k] = Uo.ld<double>(k);
       if (ok) {
 #pragma unroll
         for (int k = 0; k < NU; ++k) uprev[k] = uapp[k];
@@ -232,22 +261,22 @@ __global__ __launch_bounds__(64) M4Q_OCC void mpc_kernel(MpcArgs a) {
           for (int k = 0; k < NU; ++k) a.us[b * sUs + (long)step * NU + k] = uapp[k];
         }
       }
-      if constexpr (PLANT == PLANT_HAMILTONIAN) {
-        const cplx xn = plant_hamiltonian<NX, NU, DD>(x_cur, uapp, op0, ops, a.dt, scratch, j, jj);
-        if (ok) x_cur = xn;
-        if (ok && lane_ok) a.xs[b * sXs + (long)(step + 1) * NX + j] = xn;
-      } else if constexpr (PLANT == PLANT_GENERATOR) {
-        const cplx xn = plant_generator<NX, NU>(x_cur, uapp, op0, ops, a.dt, j);
-        if (ok) x_cur = xn;
+      if constexpr (PLANT != PLANT_NONE) {
+        const cplx xc = BasisIO<S>::template to_complex<NX, DD>(x_cur, scratch, j, jj);
+        cplx xn;
+        if constexpr (PLANT == PLANT_HAMILTONIAN) xn = plant_hamiltonian<NX, NU, DD>(xc, uapp, op0, ops, a.dt, scratch, j, jj);
+        else xn = plant_generator<NX, NU>(xc, uapp, op0, ops, a.dt, j);
+        const S rn = BasisIO<S>::template to_state<NX, DD>(xn, scratch, j, jj);
+        if (ok) x_cur = rn;
         if (ok && lane_ok) a.xs[b * sXs + (long)(step + 1) * NX + j] = xn;
       }
       // shift_guess (mpc.py:71-73,271-272): drop column 0, repeat the last
       if (ok && lane_ok) {
-        cplx nxt = Xg.ld<cplx>(1 * NX + j);
+        S nxt = Xg.ld<S>(1 * NX + j);
         for (int t = 0; t < T; ++t) {
-          const cplx cur = nxt;
-          if (t + 2 <= T) nxt = Xg.ld<cplx>((t + 2) * NX + j);
-          Xg.st<cplx>(t * NX + j, cur);
+          const S cur = nxt;
+          if (t + 2 <= T) nxt = Xg.ld<S>((t + 2) * NX + j);
+          Xg.st<S>(t * NX + j, cur);
         }
       }
       if (ok && jj < NU) {
@@ -261,17 +290,21 @@ __global__ __launch_bounds__(64) M4Q_OCC void mpc_kernel(MpcArgs a) {
       __syncthreads();
       if constexpr (PLANT == PLANT_NONE) {
         // the caller writes xs[step+1] before the next launch; inside one launch carry what is there
-        if (ok && step < a.step_end) x_cur = a.xs[b * sXs + (long)step * NX + j];
+        const bool carry = ok && step < a.step_end;
+        const cplx xc = carry ? a.xs[b * sXs + (long)step * NX + j] : czero();
+        const S rn = BasisIO<S>::template to_state<NX, DD>(xc, scratch, j, jj);
+        if (carry) x_cur = rn;
       }
     }
 
     // ---- rows that finished their run: publish the resumable state, free the slot ----
     const bool finished = active && step >= a.step_end;
     if (__any(finished)) {
+      for (int t = 0; t <= T; ++t) {
+        const cplx xc = BasisIO<S>::template to_complex<NX, DD>(Xg.ld<S>(t * NX + j), scratch, j, jj);
+        if (finished && lane_ok) a.Xg[b * sX + t * NX + j] = xc;
+      }
       if (finished) {
-        if (lane_ok) {
-          for (int t = 0; t <= T; ++t) a.Xg[b * sX + t * NX + j] = Xg.ld<cplx>(t * NX + j);
-        }
         for (int e = jj; e < T * NU; e += 16) a.Ug[b * sU + e] = Ug.ld<double>(e);
         if (jj == 0) {
           a.codes[b] = code;
@@ -300,9 +333,9 @@ __global__ __launch_bounds__(64) M4Q_OCC void linearize_kernel(LinArgs a) {
     const bool valid = q0 + g < a.B;
     const unsigned gl = valid ? g : (unsigned)(a.B - 1 - q0);
     __syncthreads();
-    stage_model(mdl, gview(a.models, q0 * a.model_stride, gl * (unsigned)a.model_stride), jj);
+    stage_model(mdl, a.models + (q0 + gl) * a.model_stride, jj);
     __syncthreads();
-    FusedProv<NX, NU, ORDER> prov;
+    FusedProv<cplx, NX, NU, ORDER> prov;
     prov.mdl = mdl;
     prov.Xg = gview(a.X, q0 * sX, gl * sX);
     prov.Ug = gview(a.U, q0 * sU, gl * sU);
@@ -335,7 +368,7 @@ __global__ __launch_bounds__(64) M4Q_OCC void qp_kernel(QpArgs a) {
   const int g = L.g, jj = L.jj, j = L.j;
   const int T = a.T;
   const int nquads = (a.B + ROWS - 1) / ROWS;
-  CostRef cost;
+  CostRef<cplx> cost;
   cost.Q = a.Q_ls; cost.Qf = a.Q_ls + (long)T * NX * NX; cost.q_stride = (long)NX * NX;
   cost.R = a.R_ls; cost.r_stride = (long)NU * NU;
   const unsigned sX = (unsigned)(T + 1) * NX, sU = (unsigned)T * NU, sG = (unsigned)T * (NX + 1) * NU;
@@ -358,9 +391,9 @@ __global__ __launch_bounds__(64) M4Q_OCC void qp_kernel(QpArgs a) {
     const GView Xo = gview(a.X_opt, q0 * sX, gl * sX);
     const GView Uo = gview(a.U_opt, q0 * sU, gl * sU);
     const bool st = valid && L.lane_ok;
-    riccati_backward<NX, NU>(prov, T, win, cost, a.flags, gains, j, st);
+    riccati_backward<cplx, NX, NU>(prov, T, win, cost, a.flags, gains, j, st);
     __syncthreads();
-    double lo0[NU], hi0[NU];
+    double lo0[NU], hi0[NU], u_first[NU];
 #pragma unroll
     for (int k = 0; k < NU; ++k) {
       const bool band = (a.flags & QP_DU_BAND) != 0 && a.u_prev != nullptr;
@@ -369,7 +402,8 @@ __global__ __launch_bounds__(64) M4Q_OCC void qp_kernel(QpArgs a) {
       hi0[k] = band ? up + a.du : a.sat;
     }
     const cplx x0 = a.x_init[b * NX + j];
-    const double obj = rollout_forward<NX, NU, true>(prov, T, x0, win, cost, a.flags, gains, a.sat, lo0, hi0, Xo, Uo, j, st);
+    const double obj = rollout_forward<cplx, NX, NU, true>(prov, T, x0, win, cost, a.flags, gains, a.sat, lo0, hi0, Xo, Uo, j, st,
+                                                              u_first);
     if (valid && jj == 0) a.cost[b] = obj;
     __syncthreads();
   }
@@ -408,9 +442,7 @@ __global__ __launch_bounds__(64) M4Q_OCC void plant_kernel(PlantArgs a) {
 // ---------------------------------------------------------------------------------------------
 // host-side launchers for this shape
 // ---------------------------------------------------------------------------------------------
-static size_t mpc_lds_bytes() {
-  return sizeof(double) * (2 * (size_t)(ROWS * MODEL_ELEMS + ROWS * SCRATCH_ELEMS + COST_ELEMS) + WLS_DOUBLES + 2);
-}
+static size_t mpc_lds_bytes(int real_path) { return real_path ? mpc_lds_layout_bytes<double>() : mpc_lds_layout_bytes<cplx>(); }
 
 template <class K>
 static int prep_lds(K kern, size_t bytes) {
@@ -421,34 +453,42 @@ static int prep_lds(K kern, size_t bytes) {
   return 0;
 }
 
-static int launch_mpc(const MpcArgs& a, int plant_kind, int grid, hipStream_t s) {
-  const size_t lds = mpc_lds_bytes();
-  int rc = 0;
-  if (plant_kind == PLANT_HAMILTONIAN) {
-    if ((rc = prep_lds(mpc_kernel<PLANT_HAMILTONIAN>, lds))) return rc;
-    hipLaunchKernelGGL(mpc_kernel<PLANT_HAMILTONIAN>, dim3(grid), dim3(64), lds, s, a);
-  } else if (plant_kind == PLANT_GENERATOR) {
-    if ((rc = prep_lds(mpc_kernel<PLANT_GENERATOR>, lds))) return rc;
-    hipLaunchKernelGGL(mpc_kernel<PLANT_GENERATOR>, dim3(grid), dim3(64), lds, s, a);
-  } else {
-    if ((rc = prep_lds(mpc_kernel<PLANT_NONE>, lds))) return rc;
-    hipLaunchKernelGGL(mpc_kernel<PLANT_NONE>, dim3(grid), dim3(64), lds, s, a);
-  }
+template <class S, int PLANT>
+static int launch_mpc_t(const MpcArgs& a, int grid, hipStream_t s) {
+  const size_t lds = mpc_lds_layout_bytes<S>();
+  int rc = prep_lds(mpc_kernel<S, PLANT>, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL((mpc_kernel<S, PLANT>), dim3(grid), dim3(64), lds, s, a);
   return -(int)hipGetLastError();
 }
 
-static int occupancy(int plant_kind) {
+static int launch_mpc(const MpcArgs& a, int plant_kind, int real_path, int grid, hipStream_t s) {
+  if (real_path) {
+    if (plant_kind == PLANT_HAMILTONIAN) return launch_mpc_t<double, PLANT_HAMILTONIAN>(a, grid, s);
+    if (plant_kind == PLANT_GENERATOR) return launch_mpc_t<double, PLANT_GENERATOR>(a, grid, s);
+    return launch_mpc_t<double, PLANT_NONE>(a, grid, s);
+  }
+  if (plant_kind == PLANT_HAMILTONIAN) return launch_mpc_t<cplx, PLANT_HAMILTONIAN>(a, grid, s);
+  if (plant_kind == PLANT_GENERATOR) return launch_mpc_t<cplx, PLANT_GENERATOR>(a, grid, s);
+  return launch_mpc_t<cplx, PLANT_NONE>(a, grid, s);
+}
+
+template <class S, int PLANT>
+static int occupancy_t() {
   int nb = 0;
-  const size_t lds = mpc_lds_bytes();
-  hipError_t e;
-  if (plant_kind == PLANT_HAMILTONIAN)
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mpc_kernel<PLANT_HAMILTONIAN>, 64, lds);
-  else if (plant_kind == PLANT_GENERATOR)
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mpc_kernel<PLANT_GENERATOR>, 64, lds);
-  else
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mpc_kernel<PLANT_NONE>, 64, lds);
-  if (e != hipSuccess) return -(int)e;
-  return nb;
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mpc_kernel<S, PLANT>, 64, mpc_lds_layout_bytes<S>());
+  return e != hipSuccess ? -(int)e : nb;
+}
+
+static int occupancy(int plant_kind, int real_path) {
+  if (real_path) {
+    if (plant_kind == PLANT_HAMILTONIAN) return occupancy_t<double, PLANT_HAMILTONIAN>();
+    if (plant_kind == PLANT_GENERATOR) return occupancy_t<double, PLANT_GENERATOR>();
+    return occupancy_t<double, PLANT_NONE>();
+  }
+  if (plant_kind == PLANT_HAMILTONIAN) return occupancy_t<cplx, PLANT_HAMILTONIAN>();
+  if (plant_kind == PLANT_GENERATOR) return occupancy_t<cplx, PLANT_GENERATOR>();
+  return occupancy_t<cplx, PLANT_NONE>();
 }
 
 static int grid_for(int B) {
@@ -457,7 +497,7 @@ static int grid_for(int B) {
 }
 
 static int launch_linearize(const LinArgs& a, hipStream_t s) {
-  const size_t lds = sizeof(double) * 2 * (size_t)(ROWS * MODEL_ELEMS);
+  const size_t lds = sizeof(cplx) * (size_t)(ROWS * MODEL_ELEMS);
   int rc = prep_lds(linearize_kernel, lds);
   if (rc) return rc;
   hipLaunchKernelGGL(linearize_kernel, dim3(grid_for(a.B)), dim3(64), lds, s, a);
@@ -470,7 +510,7 @@ static int launch_qp(const QpArgs& a, hipStream_t s) {
 }
 
 static int launch_plant(const PlantArgs& a, hipStream_t s) {
-  const size_t lds = sizeof(double) * 2 * (size_t)(ROWS * SCRATCH_ELEMS);
+  const size_t lds = sizeof(cplx) * (size_t)(ROWS * SCRATCH_ELEMS);
   if (a.kind == PLANT_HAMILTONIAN)
     hipLaunchKernelGGL(plant_kernel<PLANT_HAMILTONIAN>, dim3(grid_for(a.B)), dim3(64), lds, s, a);
   else

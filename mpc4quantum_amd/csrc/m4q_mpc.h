@@ -95,9 +95,54 @@ struct Poly {
 
 template <int NX>
 struct ModelPitch {
-  // row pitch (in complex elements) of a model block in LDS: 16 -> 17 keeps the row-owner
-  // reads (lane stride = pitch * 16 B) off a single bank
+  // row pitch (in elements) of a model block in LDS: 16 -> 17 keeps the row-owner
+  // reads (lane stride = pitch elements) off a single bank
   static constexpr int value = (NX % 16 == 0) ? NX + 1 : NX;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Hermitian operator basis used by the real path.  Slot c = a*d + b of the n = d*d state holds
+//   a == b : rho_aa            a < b : sqrt2 Re rho_ab  (symmetric part of the pair)
+//   a > b  : sqrt2 Im rho_ab   (antisymmetric part of the pair (b, a))
+// i.e. x = W r with x_ab = (r_ab - i r_ba)/sqrt2 (a < b), x_ab = (r_ba + i r_ab)/sqrt2 (a > b), x_aa = r_aa.
+// W is unitary; a Liouvillian-generated model, Hermitian states and Hermitian costs are all real in it.
+// Conversions go through a per-row LDS scratch of NX elements (one wave per workgroup: __syncthreads is
+// the wave's own LDS fence).
+// ---------------------------------------------------------------------------------------------
+template <int NX, int D>
+__device__ __forceinline__ cplx basis_to_complex(double r, double* sc, int j, int jj) {
+  const int a = j / D, b = j - (j / D) * D;
+  if (jj < NX) sc[jj] = r;
+  __syncthreads();
+  const double partner = sc[b * D + a];
+  __syncthreads();
+  const double rs = 0.70710678118654752440;
+  if (a == b) return mk(r, 0.0);
+  return a < b ? mk(r * rs, -partner * rs) : mk(partner * rs, r * rs);
+}
+template <int NX, int D>
+__device__ __forceinline__ double basis_to_real(cplx x, cplx* sc, int j, int jj) {
+  const int a = j / D, b = j - (j / D) * D;
+  if (jj < NX) sc[jj] = x;
+  __syncthreads();
+  const cplx partner = sc[b * D + a];
+  __syncthreads();
+  const double rs = 0.70710678118654752440;
+  if (a == b) return x.re;
+  return a < b ? (x.re + partner.re) * rs : (x.im - partner.im) * rs;
+}
+template <class S> struct BasisIO;
+template <> struct BasisIO<cplx> {
+  template <int NX, int D> static __device__ __forceinline__ cplx to_state(cplx x, cplx*, int, int) { return x; }
+  template <int NX, int D> static __device__ __forceinline__ cplx to_complex(cplx x, cplx*, int, int) { return x; }
+};
+template <> struct BasisIO<double> {
+  template <int NX, int D> static __device__ __forceinline__ double to_state(cplx x, cplx* sc, int j, int jj) {
+    return basis_to_real<NX, D>(x, sc, j, jj);
+  }
+  template <int NX, int D> static __device__ __forceinline__ cplx to_complex(double r, cplx* sc, int j, int jj) {
+    return basis_to_complex<NX, D>(r, reinterpret_cast<double*>(sc), j, jj);
+  }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -106,61 +151,69 @@ struct ModelPitch {
 // A_t.  rows(): for the row this lane owns, (A_t v)_j for a distributed vector v, row j of B_t and
 // Delta_t[j].  Views are positioned on this lane's instance; lane-dependent parts are 32-bit offsets.
 // ---------------------------------------------------------------------------------------------
-template <int NX, int NU, int ORDER>
+template <class S, int NX, int NU, int ORDER>
 struct FusedProv {
   static constexpr int NP = PowTab<NU, ORDER>::NP;
   static constexpr int PITCH = ModelPitch<NX>::value;
-  const cplx* mdl;    // LDS, [1+NP][NX][PITCH]: block 0 = A, block 1+p = N_p   (model.py:95-103)
+  const S* mdl;       // LDS, [1+NP][NX][PITCH]: block 0 = A, block 1+p = N_p   (model.py:95-103)
   GView Xg;           // guess trajectory [T+1][NX], positioned at element 0 of this instance
   GView Ug;           // [T][NU]
   int j;              // lane in row, clamped to NX-1
 
   struct Lin {
     double u[NU];
-    cplx xg;
+    S xg;
   };
   __device__ __forceinline__ Lin fetch(int t) const {
     Lin l;
 #pragma unroll
     for (int k = 0; k < NU; ++k) l.u[k] = Ug.ld<double>(t * NU + k);
-    l.xg = Xg.ld<cplx>(t * NX + j);
+    l.xg = Xg.ld<S>(t * NX + j);
     return l;
   }
   // A_t = A + sum_p polyu_p N_p   (linearize.py:43-48)
-  __device__ __forceinline__ void col(const Lin& l, cplx (&Ac)[NX]) const {
+  __device__ __forceinline__ void col(const Lin& l, S (&Ac)[NX]) const {
     Poly<NU, ORDER> po;
     po.eval(l.u);
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      cplx a = mdl[i * PITCH + j];
+      S a = mdl[i * PITCH + j];
 #pragma unroll
       for (int p = 0; p < NP; ++p) cmac_r(a, mdl[((1 + p) * NX + i) * PITCH + j], po.pu[p]);
       Ac[i] = a;
     }
   }
   // B_t[:,k] = sum_p (N_p x) c_kp dmono_kp(u)  (linearize.py:50-59);  Delta_t = f - A_t x - B_t u = -B_t u (:68-69)
-  __device__ __forceinline__ void rows(const Lin& l, cplx v, cplx& av, cplx (&Brow)[NU], cplx& dlt) const {
+  __device__ __forceinline__ void rows(const Lin& l, S v, S& av, S (&Brow)[NU], S& dlt) const {
     Poly<NU, ORDER> po;
     po.eval(l.u);
-    cplx nx[NP];
+    S nx[NP];
 #pragma unroll
-    for (int p = 0; p < NP; ++p) nx[p] = czero();
-    av = czero();
+    for (int p = 0; p < NP; ++p) nx[p] = zero_of<S>();
+    av = zero_of<S>();
     static_for<0, NX>([&](auto kk) {
       constexpr int k = decltype(kk)::value;
-      cplx a = mdl[j * PITCH + k];
+      S a = mdl[j * PITCH + k];
+      S np[NP];
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        const cplx np = mdl[((1 + p) * NX + j) * PITCH + k];
-        cmac_r(a, np, po.pu[p]);
-        cmac_bc<k>(nx[p], l.xg, np);
+        np[p] = mdl[((1 + p) * NX + j) * PITCH + k];
+        cmac_r(a, np[p], po.pu[p]);
       }
-      cmac_bc<k>(av, v, a);
+      if constexpr (NP <= 3) {
+        // one statement: nx[p] += lane_k(xg) * N_p[j][k] for every p, and av += lane_k(v) * A_t[j][k]
+        if constexpr (NP == 1) macN<false, false, k, k>(nx[0], l.xg, np[0], av, v, a);
+        else if constexpr (NP == 2) macN<false, false, k, k, k>(nx[0], l.xg, np[0], nx[1], l.xg, np[1], av, v, a);
+        else macN<false, false, k, k, k, k>(nx[0], l.xg, np[0], nx[1], l.xg, np[1], nx[2], l.xg, np[2], av, v, a);
+      } else {
+        mac_same_src<false, false, k, 0, NP>(nx, l.xg, np);
+        macN<false, false, k>(av, v, a);
+      }
     });
-    dlt = czero();
+    dlt = zero_of<S>();
 #pragma unroll
     for (int k = 0; k < NU; ++k) {
-      cplx b = czero();
+      S b = zero_of<S>();
 #pragma unroll
       for (int p = 0; p < NP; ++p) cmac_r(b, nx[p], po.dpu[k][p]);
       Brow[k] = b;
@@ -185,11 +238,10 @@ struct ExplicitProv {
     for (int i = 0; i < NX; ++i) Ac[i] = A_ls.ld<cplx>((l.t * NX + i) * NX + j);
   }
   __device__ __forceinline__ void rows(const Lin& l, cplx v, cplx& av, cplx (&Brow)[NU], cplx& dlt) const {
-    av = czero();
-    static_for<0, NX>([&](auto kk) {
-      constexpr int k = decltype(kk)::value;
-      cmac_bc<k>(av, v, A_ls.ld<cplx>((l.t * NX + j) * NX + k));
-    });
+    cplx arow[NX];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) arow[k] = A_ls.ld<cplx>((l.t * NX + j) * NX + k);
+    av = dot_lane_index<false, false, NX>(v, arow);
 #pragma unroll
     for (int k = 0; k < NU; ++k) Brow[k] = B_ls.ld<cplx>((l.t * NX + j) * NU + k);
     dlt = has_delta ? D_ls.ld<cplx>(l.t * NX + j) : czero();
@@ -198,21 +250,31 @@ struct ExplicitProv {
 
 // Stage costs (shared by the ensemble, wave-uniform pointers; LDS in the fused kernel).
 // Q(t) for t < T, Qf at t == T; R(t).
+template <class S>
 struct CostRef {
-  const cplx* Q;
-  const cplx* Qf;
+  const S* Q;
+  const S* Qf;
   long q_stride;   // elements between Q(t) and Q(t+1); 0 = constant
-  const cplx* R;
+  const S* R;
   long r_stride;
-  __device__ __forceinline__ const cplx* q(int t, int T) const { return t == T ? Qf : Q + (long)t * q_stride; }
-  __device__ __forceinline__ const cplx* r(int t) const { return R + (long)t * r_stride; }
+  __device__ __forceinline__ const S* q(int t, int T) const { return t == T ? Qf : Q + (long)t * q_stride; }
+  __device__ __forceinline__ const S* r(int t) const { return R + (long)t * r_stride; }
 };
 
 // The horizon window of one instance: targets (views at window column 0, element 0).
 struct Window {
-  GView xbm;   // [T+1][NX]
+  GView xbm;   // [T+1][NX] of S
   GView ubm;   // [T][NU]
 };
+
+// (Q v)_j = sum_i Q[j][i] v_i with Q row-major in memory, v distributed
+template <int NX, class S>
+__device__ __forceinline__ S qrow_times(const S* Qt, S v, int j) {
+  S qr[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) qr[i] = Qt[j * NX + i];
+  return dot_lane_index<false, false, NX>(v, qr);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Backward Riccati sweep on z = [x - xbar; 1], V = [[P, p], [p^H, pi]]  (lqr.py:28-65).
@@ -226,27 +288,22 @@ struct Window {
 // keeps loop-invariant LDS/global loads inside the horizon loops (hoisted, they cost hundreds of VGPRs)
 #define M4Q_NO_HOIST() asm volatile("" ::: "memory")
 
-template <int NX, int NU, class Prov>
-__device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const Window& win, const CostRef& cost, int flags,
+template <class S, int NX, int NU, class Prov>
+__device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const Window& win, const CostRef<S>& cost, int flags,
                                                   const GView& gains, int j, bool store_ok) {
   const bool ref = (flags & QP_REF_LQR) != 0;
-  cplx Pc[NX];
-  cplx pv = czero();
-  cplx xb_next = win.xbm.ld<cplx>(T * NX + j);        // xbar_{t+1} of the first iteration
+  S Pc[NX];
+  S pv = zero_of<S>();
+  S xb_next = win.xbm.ld<S>(T * NX + j);        // xbar_{t+1} of the first iteration
   {
-    const cplx* Qt = cost.q(T, T);
+    const S* Qt = cost.q(T, T);
 #pragma unroll
     for (int i = 0; i < NX; ++i) Pc[i] = Qt[i * NX + j];
-    if (ref) {
-      static_for<0, NX>([&](auto ii) {
-        constexpr int i = decltype(ii)::value;
-        cmac_bc<i>(pv, xb_next, cneg(Qt[j * NX + i]));
-      });
-    }
+    if (ref) pv = cneg(qrow_times<NX>(Qt, xb_next, j));
   }
   // operands of horizon index t are fetched while index t+1 is being worked on
   typename Prov::Lin lin = prov.fetch(T - 1);
-  cplx xb = win.xbm.ld<cplx>((T - 1) * NX + j);
+  S xb = win.xbm.ld<S>((T - 1) * NX + j);
   double ub[NU];
 #pragma unroll
   for (int k = 0; k < NU; ++k) ub[k] = win.ubm.ld<double>((T - 1) * NU + k);
@@ -254,70 +311,69 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
     M4Q_NO_HOIST();
     const int tn = t > 0 ? t - 1 : 0;
     const typename Prov::Lin lin_n = prov.fetch(tn);
-    const cplx xb_n = win.xbm.ld<cplx>(tn * NX + j);
+    const S xb_n = win.xbm.ld<S>(tn * NX + j);
     double ub_n[NU];
 #pragma unroll
     for (int k = 0; k < NU; ++k) ub_n[k] = win.ubm.ld<double>(tn * NU + k);
 
-    cplx Ac[NX];
+    S Ac[NX];
     prov.col(lin, Ac);
     M4Q_PHASE();
-    const cplx xb1 = xb_next;
-    cplx ax, Brow[NU], dlt;
+    const S xb1 = xb_next;
+    S ax, Brow[NU], dlt;
     prov.rows(lin, xb, ax, Brow, dlt);
     M4Q_PHASE();
 
     // affine column of the augmented dynamics
-    cplx c = ax;
+    S c = ax;
 #pragma unroll
     for (int k = 0; k < NU; ++k) cmac_r(c, Brow[k], ub[k]);
     c = ref ? csub(c, xb) : cadd(c, csub(dlt, xb1));          // lqr.py:45  |  optimize.py:41
 
-    // BhP[k] = (B^H P)[k][j]
-    cplx BhP[NU];
+    // BhP[k] = (B^H P)[k][j] = sum_i conj(B[i][k]) P[i][j]
+    S BhP[NU];
 #pragma unroll
-    for (int k = 0; k < NU; ++k) BhP[k] = czero();
+    for (int k = 0; k < NU; ++k) BhP[k] = zero_of<S>();
     static_for<0, NX>([&](auto ii) {
       constexpr int i = decltype(ii)::value;
-#pragma unroll
-      for (int k = 0; k < NU; ++k) cmac_cjbc<i>(BhP[k], Brow[k], Pc[i]);
+      mac_same_lane<true, false, i, 0, NU>(BhP, Brow, Pc[i]);
     });
-    const cplx w = cadd(matvec_h<NX>(Pc, c), pv);             // (P c + p)_j
+    const S w = cadd(matvec_h<NX>(Pc, c), pv);                // (P c + p)_j
 
     // G = R + B^H P B (replicated), h = B^H (P c + p)
-    const cplx* Rt = cost.r(t);
-    cplx g[NU][NU], ginv[NU][NU], h[NU];
+    const S* Rt = cost.r(t);
+    cplx g[NU][NU], ginv[NU][NU];
+    S h[NU];
 #pragma unroll
     for (int k = 0; k < NU; ++k) {
 #pragma unroll
       for (int l = k; l < NU; ++l) {
-        const cplx prod = cmul(BhP[k], Brow[l]);
-        const cplx rkl = Rt[k * NU + l];
-        if (l == k) g[k][l] = mk(rkl.re + rowsum<NX>(prod.re), 0.0);
-        else g[k][l] = cadd(rkl, rowsum<NX>(prod));
+        const S prod = cmul(BhP[k], Brow[l]);
+        const S rkl = Rt[k * NU + l];
+        if (l == k) g[k][l] = mk(real_of(rkl) + rowsum<NX>(real_of(prod)), 0.0);
+        else g[k][l] = as_cplx(cadd(rkl, rowsum<NX>(prod)));
       }
       h[k] = rowsum<NX>(cmul(cconj(Brow[k]), w));
     }
     herm_inverse<NU>(g, ginv);
     M4Q_PHASE();
 
-    // Hh[l] = (B^H P A_t)[l][j]
-    cplx Hh[NU];
+    // Hh[l] = (B^H P A_t)[l][j] = sum_i BhP[l][i] A_t[i][j]
+    S Hh[NU];
 #pragma unroll
-    for (int l = 0; l < NU; ++l) Hh[l] = czero();
+    for (int l = 0; l < NU; ++l) Hh[l] = zero_of<S>();
     static_for<0, NX>([&](auto ii) {
       constexpr int i = decltype(ii)::value;
-#pragma unroll
-      for (int l = 0; l < NU; ++l) cmac_bc<i>(Hh[l], BhP[l], Ac[i]);
+      mac_same_lane<false, false, i, 0, NU>(Hh, BhP, Ac[i]);
     });
-    cplx Kx[NU], kk[NU];
+    S Kx[NU], kk[NU];
 #pragma unroll
     for (int k = 0; k < NU; ++k) {
-      cplx a = czero(), b = czero();
+      S a = zero_of<S>(), b = zero_of<S>();
 #pragma unroll
       for (int l = 0; l < NU; ++l) {
-        cmac(a, ginv[k][l], Hh[l]);
-        cmac(b, ginv[k][l], h[l]);
+        cmac(a, from_cplx<S>(ginv[k][l]), Hh[l]);
+        cmac(b, from_cplx<S>(ginv[k][l]), h[l]);
       }
       Kx[k] = cneg(a);
       kk[k] = cneg(b);
@@ -325,60 +381,49 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
     if (store_ok) {
       const unsigned gt = (unsigned)t * (NX + 1) * NU;
 #pragma unroll
-      for (int k = 0; k < NU; ++k) gains.st<cplx>(gt + j * NU + k, Kx[k]);
+      for (int k = 0; k < NU; ++k) gains.st<S>(gt + j * NU + k, Kx[k]);
       if (j == 0) {
 #pragma unroll
-        for (int k = 0; k < NU; ++k) gains.st<cplx>(gt + NX * NU + k, kk[k]);
+        for (int k = 0; k < NU; ++k) gains.st<S>(gt + NX * NU + k, kk[k]);
       }
     }
 
-    // closed loop: Sx = A_t + B Kx (column j, in place), s = c + B k
-    static_for<0, NX>([&](auto ii) {
-      constexpr int i = decltype(ii)::value;
+    // closed loop: Sx = A_t + B Kx (column j, in place): Ac[i] += lane_i(B[i][k]) Kx[k];  s = c + B k
 #pragma unroll
-      for (int k = 0; k < NU; ++k) cmac_bc<i>(Ac[i], Brow[k], Kx[k]);
-    });
-    cplx s = c;
+    for (int k = 0; k < NU; ++k) mac_lane_index<false, false, 0, NX>(Ac, Brow[k], Kx[k]);
+    S s = c;
 #pragma unroll
     for (int k = 0; k < NU; ++k) cmac(s, Brow[k], kk[k]);
     M4Q_PHASE();
 
-    cplx PSc[NX];
+    S PSc[NX];
     matmul_cols<NX>(PSc, Pc, Ac);                              // P Sx
-    const cplx ws = cadd(matvec_h<NX>(Pc, s), pv);            // (P s + p)_j
+    const S ws = cadd(matvec_h<NX>(Pc, s), pv);               // (P s + p)_j
     M4Q_PHASE();
 
-    cplx RK[NU], Rk[NU];
+    S RK[NU], Rk[NU];
 #pragma unroll
     for (int k = 0; k < NU; ++k) {
-      RK[k] = czero();
-      Rk[k] = czero();
+      RK[k] = zero_of<S>();
+      Rk[k] = zero_of<S>();
 #pragma unroll
       for (int l = 0; l < NU; ++l) {
-        const cplx rkl = Rt[k * NU + l];
+        const S rkl = Rt[k * NU + l];
         cmac(RK[k], rkl, Kx[l]);
         cmac(Rk[k], rkl, kk[l]);
       }
     }
-    const cplx* Qt = cost.q(t, T);
-    cplx Pn[NX];
+    const S* Qt = cost.q(t, T);
+    S Pn[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) Pn[i] = Qt[i * NX + j];
     matmul_cols_hn_acc<NX>(Pn, Ac, PSc);                       // + Sx^H P Sx
-    static_for<0, NX>([&](auto ii) {
-      constexpr int i = decltype(ii)::value;
 #pragma unroll
-      for (int k = 0; k < NU; ++k) cmac_cjbc<i>(Pn[i], Kx[k], RK[k]);   // + Kx^H R Kx
-    });
-    cplx pn = matvec_h<NX>(Ac, ws);                            // Sx^H (P s + p)
+    for (int k = 0; k < NU; ++k) mac_lane_index<true, false, 0, NX>(Pn, Kx[k], RK[k]);   // + Kx^H R Kx
+    S pn = matvec_h<NX>(Ac, ws);                               // Sx^H (P s + p)
 #pragma unroll
     for (int k = 0; k < NU; ++k) cmac_cj(pn, Kx[k], Rk[k]);
-    if (ref) {
-      static_for<0, NX>([&](auto ii) {
-        constexpr int i = decltype(ii)::value;
-        cmac_bc<i>(pn, xb, cneg(Qt[j * NX + i]));              // - Q xbar_t   (lqr.py:54-58)
-      });
-    }
+    if (ref) pn = csub(pn, qrow_times<NX>(Qt, xb, j));        // - Q xbar_t   (lqr.py:54-58)
 #pragma unroll
     for (int i = 0; i < NX; ++i) Pc[i] = Pn[i];
     pv = pn;
@@ -396,35 +441,35 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
 // Forward rollout with clipping (lqr.py:67-79; dynamics with Delta: optimize.py:41).
 // x distributed (lane j holds x_t[j]).  WANT_COST: return the objective (replicated over the row);
 // otherwise return sum |x|^2 + sum u^2, which is finite exactly when every state and control is -
-// all the closed loop needs for its exit code 3 (mpc.py:200-203).
+// all the closed loop needs for its exit code 3 (mpc.py:200-203).  u_first receives the first control.
 // ---------------------------------------------------------------------------------------------
-template <int NX, int NU, bool WANT_COST, class Prov>
-__device__ __forceinline__ double rollout_forward(const Prov& prov, int T, cplx x0, const Window& win, const CostRef& cost,
+template <class S, int NX, int NU, bool WANT_COST, class Prov>
+__device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0, const Window& win, const CostRef<S>& cost,
                                                    int flags, const GView& gains, double sat, const double (&lo0)[NU],
                                                    const double (&hi0)[NU], const GView& Xo, const GView& Uo, int j,
-                                                   bool store_ok) {
+                                                   bool store_ok, double (&u_first)[NU]) {
   const bool ref = (flags & QP_REF_LQR) != 0;
-  cplx x = x0;
-  if (store_ok) Xo.st<cplx>(j, x);
+  S x = x0;
+  if (store_ok) Xo.st<S>(j, x);
   double cx = 0.0;     // per-lane share of the state cost
   double cu = 0.0;     // control cost (replicated)
   struct Ops {
     typename Prov::Lin lin;
-    cplx xb;
+    S xb;
     double ub[NU];
-    cplx Kx[NU];
+    S Kx[NU];
     double kre[NU];
   };
   auto load = [&](int t) {
     Ops o;
     o.lin = prov.fetch(t);
-    o.xb = win.xbm.ld<cplx>(t * NX + j);
+    o.xb = win.xbm.ld<S>(t * NX + j);
     const unsigned gt = (unsigned)t * (NX + 1) * NU;
 #pragma unroll
     for (int k = 0; k < NU; ++k) {
       o.ub[k] = win.ubm.ld<double>(t * NU + k);
-      o.Kx[k] = gains.ld<cplx>(gt + j * NU + k);
-      o.kre[k] = gains.ld<cplx>(gt + NX * NU + k).re;
+      o.Kx[k] = gains.ld<S>(gt + j * NU + k);
+      o.kre[k] = real_of(gains.ld<S>(gt + NX * NU + k));
     }
     return o;
   };
@@ -432,14 +477,14 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, cplx 
   for (int t = 0; t < T; ++t) {
     M4Q_NO_HOIST();
     const Ops nxt = load(t + 1 < T ? t + 1 : t);
-    cplx ax, Brow[NU], dlt;
+    S ax, Brow[NU], dlt;
     prov.rows(cur.lin, x, ax, Brow, dlt);
     M4Q_PHASE();
-    const cplx dx = csub(x, cur.xb);
+    const S dx = csub(x, cur.xb);
     double u[NU];
 #pragma unroll
     for (int k = 0; k < NU; ++k) {
-      const double part = cur.Kx[k].re * dx.re - cur.Kx[k].im * dx.im;
+      const double part = real_of(cmul(cur.Kx[k], dx));
       double uk = rowsum<NX>(part) + cur.kre[k] + cur.ub[k];           // lqr.py:75
       double lo = -sat, hi = sat;
       if (t == 0) {
@@ -448,37 +493,33 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, cplx 
       }
       uk = fmin(fmax(uk, lo), hi);                                     // lqr.py:76
       u[k] = uk;
+      if (t == 0) u_first[k] = uk;
     }
-    cplx xn = ref ? ax : cadd(ax, dlt);
+    S xn = ref ? ax : cadd(ax, dlt);
 #pragma unroll
     for (int k = 0; k < NU; ++k) cmac_r(xn, Brow[k], u[k]);
     if constexpr (WANT_COST) {
-      const cplx* Rt = cost.r(t);
-      const cplx e = ref ? xn : dx;
-      const cplx* Qt = cost.q(ref ? t + 1 : t, T);
-      cplx qe = czero();
-      static_for<0, NX>([&](auto ii) {
-        constexpr int i = decltype(ii)::value;
-        cmac_bc<i>(qe, e, Qt[j * NX + i]);
-      });
-      cx += e.re * qe.re + e.im * qe.im;
+      const S* Rt = cost.r(t);
+      const S e = ref ? xn : dx;
+      const S qe = qrow_times<NX>(cost.q(ref ? t + 1 : t, T), e, j);
+      cx += dot_re(e, qe);
 #pragma unroll
       for (int k = 0; k < NU; ++k) {
 #pragma unroll
         for (int l = 0; l < NU; ++l) {
           const double ek = ref ? u[k] : u[k] - cur.ub[k];
           const double el = ref ? u[l] : u[l] - cur.ub[l];
-          cu += ek * Rt[k * NU + l].re * el;
+          cu += ek * real_of(Rt[k * NU + l]) * el;
         }
       }
     } else {
-      cx = fma(xn.re, xn.re, fma(xn.im, xn.im, cx));
+      cx += norm2(xn);
 #pragma unroll
       for (int k = 0; k < NU; ++k) cu = fma(u[k], u[k], cu);
     }
     x = xn;
     if (store_ok) {
-      Xo.st<cplx>((t + 1) * NX + j, x);
+      Xo.st<S>((t + 1) * NX + j, x);
       if (j == 0) {
 #pragma unroll
         for (int k = 0; k < NU; ++k) Uo.st<double>(t * NU + k, u[k]);
@@ -489,14 +530,9 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, cplx 
   }
   if constexpr (WANT_COST) {
     if (!ref) {
-      const cplx e = csub(x, win.xbm.ld<cplx>(T * NX + j));
-      const cplx* Qt = cost.q(T, T);
-      cplx qe = czero();
-      static_for<0, NX>([&](auto ii) {
-        constexpr int i = decltype(ii)::value;
-        cmac_bc<i>(qe, e, Qt[j * NX + i]);
-      });
-      cx += e.re * qe.re + e.im * qe.im;
+      const S e = csub(x, win.xbm.ld<S>(T * NX + j));
+      const S qe = qrow_times<NX>(cost.q(T, T), e, j);
+      cx += dot_re(e, qe);
     }
   }
   return rowsum<NX>(cx) + cu;
@@ -579,28 +615,38 @@ __device__ __forceinline__ void ls_block(const ZV& z, int base, const double* C,
 
 // Fast path when every cost block is diagonal (real diagonal Q, Qf, R - the case of all reference
 // scenarios): the block products collapse to one weight per Z entry.  Each lane walks ITS state element
-// over the horizon in natural (coalesced) order and looks the weight of the Z slot that element lands in
-// up in a 2n-entry table, so the reference's layout quirk costs two integer divisions per element.
-// wq/wqf: 2*NX weights, wr: 2*NU weights (LDS or L1-resident).
-template <int NX, int NU>
+// over the horizon in natural (coalesced) order and looks the weight of the Z slot(s) that element lands
+// in up in a 2n-entry table, so the reference's layout quirk costs a few integer divisions per element.
+// wq/wqf: 2*NX weights, wr: 2*NU weights (LDS).  S = double: the lane's element is a Hermitian-basis
+// coordinate that feeds two Z slots (Re or Im of rho_ab and rho_ba) with coefficient 1/sqrt2 each.
+template <class S, int NX, int NU, int D>
 __device__ __forceinline__ void line_search_diag(const ZView<NX, NU>& z, const double* wq, const double* wqf,
                                                  const double* wr, int jj, double& alpha, double& step_norm) {
   const int T = z.T;
   const int nxt = NX * (T + 1);
   double num = 0.0, den = 0.0, nrm = 0.0;
+  auto weight = [&](int q) {
+    const int blk = q / (2 * NX);
+    const int r = q - blk * (2 * NX);
+    return (blk == T ? wqf : wq)[r];
+  };
   if (jj < NX) {
+    const int a = jj / D, b = jj - (jj / D) * D;
+    const int partner = b * D + a;
     for (int t = 0; t <= T; ++t) {
-      const cplx g = z.Xg.template ld<cplx>(t * NX + jj), o = z.Xo.template ld<cplx>(t * NX + jj),
-                 tg = z.Xt.template ld<cplx>(t * NX + jj);
-      const int q0 = jj * (T + 1) + t;          // Z slot of the real part; the imaginary part sits nxt further
-#pragma unroll
-      for (int part = 0; part < 2; ++part) {
-        const int q = q0 + part * nxt;
-        const int blk = q / (2 * NX);
-        const int r = q - blk * (2 * NX);
-        const double w = (blk == T ? wqf : wq)[r];
-        const double e = part ? g.im - tg.im : g.re - tg.re;
-        const double d = part ? o.im - g.im : o.re - g.re;
+      const S g = z.Xg.template ld<S>(t * NX + jj), o = z.Xo.template ld<S>(t * NX + jj), tg = z.Xt.template ld<S>(t * NX + jj);
+      const int q0 = jj * (T + 1) + t;          // Z slot of Re x_jj'; Im sits nxt further
+      if constexpr (sizeof(S) == sizeof(cplx)) {
+        const cplx gc = as_cplx(g), oc = as_cplx(o), tc = as_cplx(tg);
+        const double w0 = weight(q0), w1 = weight(q0 + nxt);
+        const double e0 = gc.re - tc.re, d0 = oc.re - gc.re, e1 = gc.im - tc.im, d1 = oc.im - gc.im;
+        num = fma(w0 * e0, d0, fma(w1 * e1, d1, num));
+        den = fma(w0 * d0, d0, fma(w1 * d1, d1, den));
+        nrm = fma(d0, d0, fma(d1, d1, nrm));
+      } else {
+        const double e = real_of(g) - real_of(tg), d = real_of(o) - real_of(g);
+        const int off = a > b ? nxt : 0;        // antisymmetric coordinates live in the imaginary halves
+        const double w = a == b ? weight(q0) : 0.5 * (weight(q0 + off) + weight(partner * (T + 1) + t + off));
         num = fma(w * e, d, num);
         den = fma(w * d, d, den);
         nrm = fma(d, d, nrm);
@@ -741,17 +787,6 @@ __device__ __forceinline__ void expm_cols(cplx (&A)[N], int j) {
   }
 #pragma unroll
   for (int i = 0; i < N; ++i) A[i] = Pm[i];
-}
-
-// y_j = sum_i M[i][j] v_i  (M column-owned, v distributed) = (M^T v)_j
-template <int N>
-__device__ __forceinline__ cplx matvec_t(const cplx (&M)[N], cplx v) {
-  cplx y = czero();
-  static_for<0, N>([&](auto ii) {
-    constexpr int i = decltype(ii)::value;
-    cmac_bc<i>(y, v, M[i]);
-  });
-  return y;
 }
 
 // Plant kinds (mirrored in include/m4q.h)

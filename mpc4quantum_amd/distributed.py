@@ -83,4 +83,4 @@ def mpc_batch_sharded(x0, models, dim_u, order, X_targ, U_targ, clock, plant_op0
     if rank != dst:
         return None
     parts = [g for g in gathered if g is not None]
-    return {k: np.concatenate([g[k] for g in parts], axis=0) for k in parts[0]}
+    return {k: np.concatenate([g[k] for g in parts], axis=0) for k in parts[0] if isinstance(parts[0][k], np.ndarray)}

@@ -183,7 +183,8 @@ class _HeldControl:
 
 
 def mpc_batch(x0, models, dim_u, order, X_targ, U_targ, clock, plant_op0, plant_ops, Q, R, Qf, sat, du=None,
-              max_iter=100, warm_start=True, qp_flags=None, plant_kind=_lib.PLANT_HAMILTONIAN, device=-1, session=None):
+              max_iter=100, warm_start=True, qp_flags=None, plant_kind=_lib.PLANT_HAMILTONIAN, device=-1, session=None,
+              force_complex=False):
     """B independent closed loops in one launch.
     x0 [B, n]; models [B|1, n, n(1+P)]; X_targ (n, cols) / U_targ (m, cols) shared (or [B, ...] each);
     plant_op0 [B|1, k, k], plant_ops [B|1, m, k, k].  Returns a dict: xs [B, n, n_steps+1], us [B, m, n_steps]
@@ -209,11 +210,13 @@ def mpc_batch(x0, models, dim_u, order, X_targ, U_targ, clock, plant_op0, plant_
     cols = min(X_targ.shape[-1], ns + T + 1)
     own = session is None
     sess = session or EnsembleSession(Bn, n, dim_u, order, T, ns, clock.dt, sat, du, max_iter, warm_start, qp_flags,
-                                      plant_kind, models.shape[0] > 1, per_plant, per_targ, cols, device=device)
+                                      plant_kind, models.shape[0] > 1, per_plant, per_targ, cols, device=device,
+                                      force_complex=force_complex)
     try:
         sess.load_problem(models, x0, X_targ, U_targ, Q, R, Qf, op0, ops)
         sess.run(0, ns)
         res = sess.results()
+        res["path"] = sess.path()
     finally:
         if own:
             sess.close()

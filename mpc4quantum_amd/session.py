@@ -17,7 +17,7 @@ _DTYPES = {
 class EnsembleSession:
     def __init__(self, B, dim_x, dim_u, order, horizon, n_steps, dt, sat, du=None, max_iter=100, warm_start=True,
                  qp_flags=None, plant_kind=_lib.PLANT_HAMILTONIAN, model_per_instance=False, plant_per_instance=False,
-                 target_per_instance=False, target_cols=None, ls_tol=1e-4, device=-1):
+                 target_per_instance=False, target_cols=None, ls_tol=1e-4, device=-1, force_complex=False):
         if sat is None:
             raise TypeError("sat is required (the reference negates it unconditionally, optimize.py:43 / lqr.py:76)")
         p = _lib.Problem()
@@ -28,6 +28,7 @@ class EnsembleSession:
         p.model_per_instance, p.plant_per_instance = int(model_per_instance), int(plant_per_instance)
         p.target_per_instance = int(target_per_instance)
         p.target_cols = int(target_cols if target_cols is not None else n_steps + horizon + 1)
+        p.reserved = _lib.OPT_FORCE_COMPLEX if force_complex else 0
         p.dt, p.sat, p.du, p.ls_tol = float(dt), float(sat), float(du if du is not None else 0.0), float(ls_tol)
         self.problem = p
         self.B = int(B)
@@ -88,6 +89,10 @@ class EnsembleSession:
         n = C.c_int32()
         _lib.check(self._L.m4q_session_kernel_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def path(self):
+        """'real' if the uploaded problem runs in the Hermitian operator basis with real arithmetic, else 'complex'."""
+        return "real" if _lib.check(self._L.m4q_session_path(self._h)) == 1 else "complex"
 
     def info(self):
         hbm = C.c_int64()

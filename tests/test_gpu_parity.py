@@ -287,13 +287,16 @@ def _envelope(p, idx, xs, us, eps=1e-14):
     return eu, ex
 
 
+@pytest.mark.parametrize("path", ["real", "complex"])
 @pytest.mark.parametrize("cfg,order,batch,horizon", [(1, 1, 1, None), (1, 2, 1, None), (2, 1, 6, None), (3, 1, 5, 16),
                                                       (3, 2, 3, 12), (4, 1, 3, 10)])
-def test_closed_loop_vs_oracle(cfg, order, batch, horizon):
-    """Free-running closed loop, all MPC steps in one launch."""
+def test_closed_loop_vs_oracle(cfg, order, batch, horizon, path):
+    """Free-running closed loop, all MPC steps in one launch, on both arithmetic paths: the Hermitian-basis real
+    path these (Liouvillian) models qualify for, and the general complex path forced with M4Q_OPT_FORCE_COMPLEX."""
     p = configs.build(cfg, batch=batch, order=order, horizon=horizon)
     idx = np.arange(batch)
-    res = _gpu_batch(p, idx)
+    res = _gpu_batch(p, idx, force_complex=(path == "complex"))
+    assert res["path"] == path
     xs, us, codes, solves = _oracle_batch(p, idx)
     assert np.array_equal(res["exit_codes"], codes)
     assert np.array_equal(res["qp_solves"], solves)
@@ -308,8 +311,9 @@ def test_closed_loop_vs_oracle(cfg, order, batch, horizon):
     assert np.abs(res["us"]).max() <= p["sat"] * (1 + 1e-15)
 
 
+@pytest.mark.parametrize("path", ["real", "complex"])
 @pytest.mark.parametrize("cfg,order,batch,horizon", [(1, 2, 1, None), (3, 1, 4, None), (4, 1, 2, 12)])
-def test_closed_loop_stepwise_teacher_forced(cfg, order, batch, horizon):
+def test_closed_loop_stepwise_teacher_forced(cfg, order, batch, horizon, path):
     """Every MPC step of the run, started from the ORACLE's state (states, controls, SQP guesses) through the
     session's checkpoint/restore fields.  The outputs of the step - applied control us[k], next state xs[k+1],
     QP-solve count - must match to 1e-10 whatever the conditioning of the loop; the shifted SQP
@@ -324,10 +328,11 @@ def test_closed_loop_stepwise_teacher_forced(cfg, order, batch, horizon):
     q = dict(p)
     q["models"] = models
     ns, T = p["n_steps"], p["horizon"]
-    sess = _session(q, batch)
+    sess = _session(q, batch, force_complex=(path == "complex"))
     try:
         sess.load_problem(models, p["x0"][idx], p["X_targ"], p["U_targ"], p["Q"], p["R"], p["Qf"], p["plant_op0"],
                           p["plant_ops"])
+        assert sess.path() == path
         xs_t, us_t = np.swapaxes(xs, 1, 2), np.swapaxes(us, 1, 2)          # time-major, as the C ABI holds them
         worst = 0.0
         for k in range(ns):
@@ -352,13 +357,17 @@ def test_closed_loop_stepwise_teacher_forced(cfg, order, batch, horizon):
         sess.close()
 
 
-def test_checkpoint_resume_is_bit_identical():
-    """state() after step 7, restore() into a fresh session, run the rest: identical bits to an uninterrupted run."""
+@pytest.mark.parametrize("path", ["complex", "real"])
+def test_checkpoint_resume(path):
+    """state() after step 7, restore() into a fresh session, run the rest.  On the complex path the result has
+    identical bits to an uninterrupted run; on the real path the checkpoint holds the guess in the original complex
+    basis, and the two basis changes cost one rounding each."""
     p = configs.build(3, batch=6, horizon=16)
     idx = np.arange(6)
-    full = _gpu_batch(p, idx)
-    s1 = _session(p, 6)
-    s2 = _session(p, 6)
+    fc = path == "complex"
+    full = _gpu_batch(p, idx, force_complex=fc)
+    s1 = _session(p, 6, force_complex=fc)
+    s2 = _session(p, 6, force_complex=fc)
     try:
         for s in (s1, s2):
             s.load_problem(p["models"], p["x0"], p["X_targ"], p["U_targ"], p["Q"], p["R"], p["Qf"], p["plant_op0"],
@@ -370,8 +379,11 @@ def test_checkpoint_resume_is_bit_identical():
     finally:
         s1.close()
         s2.close()
-    assert np.array_equal(np.swapaxes(r2["xs"], 1, 2), full["xs"])
-    assert np.array_equal(np.swapaxes(r2["us"], 1, 2), full["us"])
+    if fc:
+        assert np.array_equal(np.swapaxes(r2["xs"], 1, 2), full["xs"])
+        assert np.array_equal(np.swapaxes(r2["us"], 1, 2), full["us"])
+    else:
+        assert rel(np.swapaxes(r2["xs"], 1, 2), full["xs"]) <= 1e-9 and rel(np.swapaxes(r2["us"], 1, 2), full["us"]) <= 1e-9
     assert np.all(r2["steps_done"] == p["n_steps"])
 
 
@@ -401,6 +413,7 @@ def test_closed_loop_dense_costs_general_line_search():
     p["R"] = 0.5 * (p["R"] + p["R"].T)
     idx = np.arange(3)
     res = _gpu_batch(p, idx)
+    assert res["path"] == "complex"          # W^H Q W is not real: the problem does not qualify for the real path
     xs, us, codes, solves = _oracle_batch(p, idx)
     assert np.array_equal(res["qp_solves"], solves)
     assert rel(res["us"][:, :, 0], us[:, :, 0]) <= 1e-10 and rel(res["xs"][:, :, 1], xs[:, :, 1]) <= 1e-10
@@ -468,6 +481,27 @@ def test_mpc_exit_condition_and_exit_code_1():
     assert code == co == 1
     assert xs.shape == xo.shape and us.shape == uo.shape and len(clock.ts_sim) == len(oclk.ts_sim)
     assert rel(xs, xo) <= 1e-8 and rel(us, uo) <= 1e-8
+
+
+def test_real_and_complex_paths_agree_and_fallback_rules():
+    """Same problem on both paths: identical QP-solve counts, results equal to rounding.  A model that does not
+    preserve Hermiticity, or a non-Hermitian initial state, silently takes the complex path."""
+    p = configs.build(3, batch=8, horizon=12, n_steps=6)
+    idx = np.arange(8)
+    r = _gpu_batch(p, idx)
+    c = _gpu_batch(p, idx, force_complex=True)
+    assert r["path"] == "real" and c["path"] == "complex"
+    assert np.array_equal(r["qp_solves"], c["qp_solves"])
+    assert rel(r["us"], c["us"]) <= 1e-7 and rel(r["xs"], c["xs"]) <= 1e-7
+    assert rel(r["us"][:, :, 0], c["us"][:, :, 0]) <= 1e-11
+    q = dict(p)
+    q["models"] = p["models"].copy()
+    q["models"][3, 0, 1] += 1e-3j
+    assert _gpu_batch(q, idx)["path"] == "complex"
+    q = dict(p)
+    q["x0"] = p["x0"].copy()
+    q["x0"][2, 1] += 1e-6
+    assert _gpu_batch(q, idx)["path"] == "complex"
 
 
 def test_exit_code_3_on_nonfinite_model():
