@@ -69,5 +69,7 @@ if __name__ == "__main__":
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--jobs", type=int, default=None)
     ap.add_argument("--shfl", action="store_true", help="debug build: row broadcasts through ds_bpermute instead of DPP")
+    ap.add_argument("--define", action="append", default=[], help="extra -D for the kernel objects (tuning experiments)")
     a = ap.parse_args()
-    print(build(a.force, a.jobs, ["-DM4Q_BCAST_SHFL"] if a.shfl else []))
+    extra = (["-DM4Q_BCAST_SHFL"] if a.shfl else []) + ["-D" + d for d in a.define]
+    print(build(a.force or bool(extra), a.jobs, extra))

@@ -27,7 +27,8 @@ struct MpcArgs {
   cplx* Xg; double* Ug;                     // per-instance SQP guess  [B][T+1][n] complex, [B][T][m] (resumable state)
   // per resident row (grid*4 of them): working guess, QP solution, gains (S)
   void* ws_Xg; double* ws_Ug; void* ws_Xo; double* ws_Uo; void* ws_gains;
-  int* queue;                               // next instance to hand out; zeroed before every launch
+  int* queue;                               // next work item to hand out; zeroed before every launch
+  int* head_done;                           // [B] set when an instance's head item (steps < 2) has been published; zeroed likewise
 };
 
 struct LinArgs {

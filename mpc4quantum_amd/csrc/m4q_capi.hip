@@ -166,7 +166,7 @@ struct m4q_session {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int grid = 1;
   DevBuf f[M4Q_F_COUNT];
-  DevBuf Cq, Cqf, Cr, Wls, wsXg, wsUg, wsXo, wsUo, wsG, queue;
+  DevBuf Cq, Cqf, Cr, Wls, wsXg, wsUg, wsXo, wsUo, wsG, queue, head_done;
   size_t fbytes[M4Q_F_COUNT]{};
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
   double ms_total = 0.0;
@@ -279,6 +279,7 @@ int m4q_session_create(const m4q_problem* p, int32_t B, int32_t device, m4q_sess
   if (!rc) rc = s->wsXg.alloc(rows * (T + 1) * n * C);
   if (!rc) rc = s->wsUg.alloc(rows * T * m * 8);
   if (!rc) rc = s->queue.alloc(64);
+  if (!rc) rc = s->head_done.alloc((size_t)B * 4);
   if (!rc) rc = s->wsXo.alloc(rows * (T + 1) * n * C);
   if (!rc) rc = s->wsUo.alloc(rows * T * m * 8);
   if (!rc) rc = s->wsG.alloc(rows * T * (n + 1) * m * C);
@@ -487,7 +488,9 @@ int m4q_session_run(m4q_session* s, int32_t step_begin, int32_t step_end) {
   a.ws_Xg = s->wsXg.p; a.ws_Ug = (double*)s->wsUg.p;
   a.ws_Xo = s->wsXo.p; a.ws_Uo = (double*)s->wsUo.p; a.ws_gains = s->wsG.p;
   a.queue = (int*)s->queue.p;
+  a.head_done = (int*)s->head_done.p;
   HIP_TRY(hipMemsetAsync(s->queue.p, 0, 64, s->stream));
+  HIP_TRY(hipMemsetAsync(s->head_done.p, 0, (size_t)s->B * 4, s->stream));
   if (step_begin == 0) {
     HIP_TRY(hipMemsetAsync(s->f[M4Q_F_QP_SOLVES].p, 0, s->fbytes[M4Q_F_QP_SOLVES], s->stream));
     HIP_TRY(hipMemsetAsync(s->f[M4Q_F_CODES].p, 0, s->fbytes[M4Q_F_CODES], s->stream));

@@ -87,6 +87,17 @@ __device__ __forceinline__ GView gview(const T* p, long uniform_elems, unsigned 
   return v;
 }
 
+// ---- ordering inside one wavefront -------------------------------------------------------------
+// A workgroup is ONE wavefront.  Lanes exchange data through global memory (workspace) and LDS; the
+// hardware performs a wave's memory instructions in issue order, so all that is needed between a
+// store by one lane and a load by another is that the COMPILER keeps their order: a wavefront-scope
+// release/acquire fence emits no instruction (no vmcnt(0) drain, no s_barrier), unlike __syncthreads().
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---- compile-time loop with an integral_constant index (DPP controls are immediates) ----
 template <int I>
 using ic = std::integral_constant<int, I>;

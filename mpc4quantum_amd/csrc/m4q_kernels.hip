@@ -32,7 +32,12 @@ constexpr int ROWS = 4;                                    // instances per wave
 #ifndef M4Q_WAVES
 #define M4Q_WAVES ((M4Q_NX <= 4) ? 4 : (M4Q_NX <= 9) ? 2 : 1)
 #endif
+#ifndef M4Q_WAVES_REAL
+#define M4Q_WAVES_REAL ((M4Q_NX <= 4) ? 4 : (M4Q_NX <= 9) ? 2 : 1)
+#endif
 #define M4Q_OCC __attribute__((amdgpu_waves_per_eu(M4Q_WAVES, 8)))
+template <class S> struct WavesFor { static constexpr int value = M4Q_WAVES; };
+template <> struct WavesFor<double> { static constexpr int value = M4Q_WAVES_REAL; };
 
 extern __shared__ __align__(16) unsigned char m4q_lds_raw[];
 
@@ -65,6 +70,14 @@ struct LaneGeo {
 // ---------------------------------------------------------------------------------------------
 // The fused closed loop (replaces mpc.py:161-292).
 //
+// Work items: an instance's run is cut at MPC step 2.  Steps 0-1 iterate the SQP to convergence (14..100
+// solves, data dependent); steps >= 2 are one solve each (mpc.py:208-212).  The queue hands out all the
+// "head" items (steps [step_begin, 2)) first, then the uniform "tail" items (steps [2, step_end)), so the
+// long, uneven pieces are packed first and the launch drains on short uniform ones.  A tail item may be
+// drawn by another workgroup - possibly on another XCD - than the one that ran its head: the head
+// publishes the instance state with an agent-scope release and a flag, the tail polls the flag (without
+// blocking its wavefront) and acquires.
+//
 // Scheduling: the wavefront is a four-slot machine.  Every DPP row pulls its OWN next instance from a
 // device-wide atomic queue and carries its own (instance, MPC step, SQP iteration); one pass of the main
 // loop performs one QP solve for each row at whatever point of its run that row has reached.  SQP
@@ -86,7 +99,7 @@ constexpr size_t mpc_lds_layout_bytes() {
 __device__ __forceinline__ int row_bcast_int(int v) { return __shfl(v, 0, 16); }
 
 template <class S, int PLANT>
-__global__ __launch_bounds__(64) M4Q_OCC void mpc_kernel(MpcArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>::value, 8))) void mpc_kernel(MpcArgs a) {
   // LDS: [4 x scratch (complex)] [4 x model (S)] [Q Qf R (S)] [line-search weights]
   cplx* scratch = reinterpret_cast<cplx*>(m4q_lds_raw);
   S* lds = reinterpret_cast<S*>(scratch + ROWS * SCRATCH_ELEMS);
@@ -124,73 +137,104 @@ __global__ __launch_bounds__(64) M4Q_OCC void mpc_kernel(MpcArgs a) {
   const bool band = (a.flags & QP_DU_BAND) != 0;
   const S* x_targ = static_cast<const S*>(a.x_targ);
 
+  // cut the run in two work items per instance when the launch covers both regimes
+  const bool two_phase = a.step_begin < 2 && a.step_end > 2;
+  const int n_items = two_phase ? 2 * a.B : a.B;
+
   // per-row state (uniform inside a row)
   long b = 0;
-  bool active = false, need_new = true;
+  bool active = false, need_new = true, pending = false;
   int step = 0, iter = 0, code = 0, done_steps = 0;
+  int row_begin = a.step_begin, row_end = a.step_end;
   S x_cur = zero_of<S>();
   double uprev[NU];
 #pragma unroll
   for (int k = 0; k < NU; ++k) uprev[k] = 0.0;
   GView xt = gview(x_targ, 0, 0), ut = gview(a.u_targ, 0, 0), op0 = gview(a.op0, 0, 0), ops = gview(a.ops, 0, 0);
-  __syncthreads();
+  wave_sync();
 
   while (true) {
-    // ---- rows without work draw the next instance ----
-    if (__any(need_new)) {
+    // ---- rows without work draw the next item; tail items wait (without blocking) for their head ----
+    if (__any(need_new || pending)) {
       int nb = 0;
       if (need_new && jj == 0) nb = atomicAdd(a.queue, 1);
       nb = row_bcast_int(nb);
-      const bool fresh = need_new && nb < a.B;
-      if (need_new) { active = fresh; need_new = false; }
-      if (fresh) b = nb;
-      __syncthreads();
+      if (need_new) {
+        need_new = false;
+        if (nb < n_items) {
+          const bool tail = two_phase && nb >= a.B;
+          b = tail ? nb - a.B : nb;
+          row_begin = tail ? 2 : a.step_begin;
+          row_end = (two_phase && !tail) ? 2 : a.step_end;
+          pending = true;
+        }
+      }
+      // a tail item starts once the head of its instance has been published
+      int ready = 1;
+      if (pending && two_phase && row_begin == 2 && jj == 0)
+        ready = __hip_atomic_load(a.head_done + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ready = row_bcast_int(ready);
+      const bool fresh = pending && ready != 0;
+      if (__any(fresh && two_phase && row_begin == 2)) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      if (fresh) { pending = false; active = true; }
+      wave_sync();
       if (fresh) {
         stage_model(mdl, static_cast<const S*>(a.models) + b * a.model_stride, jj);
         xt = gview(x_targ, 0, (unsigned)(b * a.xt_stride));
         ut = gview(a.u_targ, 0, (unsigned)(b * a.ut_stride));
         op0 = gview(a.op0, 0, (unsigned)(b * a.op0_stride));
         ops = gview(a.ops, 0, (unsigned)(b * a.ops_stride));
-        step = a.step_begin;
+        step = row_begin;
         iter = 0;
         code = 0;
         done_steps = 0;
       }
-      if (a.step_begin == 0) {
-        if (fresh) {
+      if (__any(fresh && row_begin == 0)) {
+        if (fresh && row_begin == 0) {
           // X_guess = tile(x0), U_guess = 0 (mpc.py:141-142); xs[0] = x0 (:160)
           const S x0 = static_cast<const S*>(a.x0s)[b * NX + j];
           x_cur = x0;
           if (lane_ok) {
+#pragma unroll 8
             for (int t = 0; t <= T; ++t) Xg.st<S>(t * NX + j, x0);
             a.xs[b * sXs + j] = a.x0c[b * NX + j];
           }
           for (int e = jj; e < T * NU; e += 16) Ug.st<double>(e, 0.0);
         }
-      } else {
-        // resume: the SQP guess, state and exit code of a previous launch (fields X_GUESS/U_GUESS/XS/US/CODES).
+      }
+      if (__any(fresh && row_begin != 0)) {
+        // resume: the SQP guess, state and exit code of an earlier item or launch (fields X_GUESS/U_GUESS/XS/US/CODES).
         // The stored guess is complex in the original basis; the basis change needs every lane (LDS exchange).
+        const bool rs = fresh && row_begin != 0;
+#pragma unroll 4
         for (int t = 0; t <= T; ++t) {
-          const cplx xc = fresh ? a.Xg[b * sX + t * NX + j] : czero();
+          const cplx xc = rs ? a.Xg[b * sX + t * NX + j] : czero();
           const S r = BasisIO<S>::template to_state<NX, DD>(xc, scratch, j, jj);
-          if (fresh && lane_ok) Xg.st<S>(t * NX + j, r);
+          if (rs && lane_ok) Xg.st<S>(t * NX + j, r);
         }
-        const cplx xc = fresh ? a.xs[b * sXs + (long)a.step_begin * NX + j] : czero();
+        const cplx xc = rs ? a.xs[b * sXs + (long)row_begin * NX + j] : czero();
         const S r = BasisIO<S>::template to_state<NX, DD>(xc, scratch, j, jj);
-        if (fresh) {
+        if (rs) {
           x_cur = r;
           for (int e = jj; e < T * NU; e += 16) Ug.st<double>(e, a.Ug[b * sU + e]);
           code = a.codes[b];
           done_steps = a.steps_done[b];
 #pragma unroll
-          for (int k = 0; k < NU; ++k) uprev[k] = a.us[b * sUs + (long)(a.step_begin - 1) * NU + k];
-          if (code != 0) step = a.step_end;       // finished earlier (exit code set by the host or the device)
+          for (int k = 0; k < NU; ++k) uprev[k] = a.us[b * sUs + (long)(row_begin - 1) * NU + k];
+          if (code != 0) step = row_end;          // finished earlier (exit code set by the host or the device)
         }
       }
-      __syncthreads();
+      wave_sync();
     }
-    if (!__any(active)) break;
-    const bool running = active && step < a.step_end;
+    if (!__any(active || pending)) break;
+    if (!__any(active)) {
+      __builtin_amdgcn_s_sleep(8);                 // only tail items whose head is still running: poll again
+      continue;
+    }
+    const bool running = active && step < row_end;
 
     // ---- one QP solve per row ----
     // target window: X_ref = X_targ[:, :T+1] for steps 0 and 1, then X_targ[:, step-1:...] (mpc.py:145,276)
@@ -208,17 +252,25 @@ __global__ __launch_bounds__(64) M4Q_OCC void mpc_kernel(MpcArgs a) {
     }
     const bool use_ls = !(a.warm_start && step > 1);        // mpc.py:208-213
     const bool st = running && lane_ok;
-    riccati_backward<S, NX, NU>(prov, T, win, cost, a.flags, gains, j, st);
-    __syncthreads();
+#ifndef M4Q_EXP
+#define M4Q_EXP 0
+#endif
+    // M4Q_EXP: timing-only ablation builds (results are wrong): 1 fixed 3 SQP iterations, 2 no backward,
+    // 4 no forward, 8 no line search, 16 no guess update, 32 no plant/shift
+    if constexpr (!(M4Q_EXP & 2)) riccati_backward<S, NX, NU>(prov, T, win, cost, a.flags, gains, j, st);
+    wave_sync();
     double uapp[NU];
-    const double chk = rollout_forward<S, NX, NU, false>(prov, T, x_cur, win, cost, a.flags, gains, a.sat, lo0, hi0, Xo, Uo, j, st,
-                                                         uapp);
-    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NU; ++k) uapp[k] = 0.0;
+    double chk = 0.0;
+    if constexpr (!(M4Q_EXP & 4))
+      chk = rollout_forward<S, NX, NU, false>(prov, T, x_cur, win, cost, a.flags, gains, a.sat, lo0, hi0, Xo, Uo, j, st, uapp);
+    wave_sync();
     const bool fail = !finite_d(chk);                      // mpc.py:200-203
     if (running) ++iter;
     double alpha = 1.0;
     bool fin = true;
-    if (__any(running && use_ls)) {
+    if (!(M4Q_EXP & 8) && __any(running && use_ls)) {
       ZView<NX, NU> z;
       z.T = T; z.Xg = Xg; z.Xo = Xo; z.Xt = win.xbm; z.Ug = Ug; z.Uo = Uo; z.Ut = win.ubm;
       double al = 1.0, stepn = 0.0;
@@ -229,23 +281,27 @@ __global__ __launch_bounds__(64) M4Q_OCC void mpc_kernel(MpcArgs a) {
       }
       if (use_ls) { alpha = al; fin = stepn < a.ls_tol; }   // mpc.py:224
     }
-    __syncthreads();
+    if (M4Q_EXP & 1) { fin = !use_ls || iter >= 3; alpha = 1.0; }
+    wave_sync();
     const bool upd = running && !fail;
     // X_guess += alpha (X_opt - X_guess) (mpc.py:228-229)
-    if (upd && lane_ok) {
+    // (these small per-element passes are latency bound: unrolled so that several loads are in flight)
+    if (!(M4Q_EXP & 16) && upd && lane_ok) {
+#pragma unroll 8
       for (int t = 0; t <= T; ++t) {
         const S xg = Xg.ld<S>(t * NX + j), xo = Xo.ld<S>(t * NX + j);
         Xg.st<S>(t * NX + j, cadd(xg, cscale(csub(xo, xg), alpha)));
       }
     }
     if (upd) {
+#pragma unroll 4
       for (int e = jj; e < T * NU; e += 16) {
         const double ug = Ug.ld<double>(e);
         Ug.st<double>(e, ug + alpha * (Uo.ld<double>(e) - ug));
       }
     }
     const bool step_done = running && (fail || fin || iter >= a.max_iter);
-    __syncthreads();
+    wave_sync();
 
     // ---- rows that finished their MPC step: apply, propagate, shift ----
     if (__any(step_done)) {
@@ -261,7 +317,7 @@ __global__ __launch_bounds__(64) M4Q_OCC void mpc_kernel(MpcArgs a) {
           for (int k = 0; k < NU; ++k) a.us[b * sUs + (long)step * NU + k] = uapp[k];
         }
       }
-      if constexpr (PLANT != PLANT_NONE) {
+      if constexpr (PLANT != PLANT_NONE && !(M4Q_EXP & 32)) {
         const cplx xc = BasisIO<S>::template to_complex<NX, DD>(x_cur, scratch, j, jj);
         cplx xn;
         if constexpr (PLANT == PLANT_HAMILTONIAN) xn = plant_hamiltonian<NX, NU, DD>(xc, uapp, op0, ops, a.dt, scratch, j, jj);
@@ -271,35 +327,45 @@ __global__ __launch_bounds__(64) M4Q_OCC void mpc_kernel(MpcArgs a) {
         if (ok && lane_ok) a.xs[b * sXs + (long)(step + 1) * NX + j] = xn;
       }
       // shift_guess (mpc.py:71-73,271-272): drop column 0, repeat the last
-      if (ok && lane_ok) {
-        S nxt = Xg.ld<S>(1 * NX + j);
-        for (int t = 0; t < T; ++t) {
-          const S cur = nxt;
-          if (t + 2 <= T) nxt = Xg.ld<S>((t + 2) * NX + j);
-          Xg.st<S>(t * NX + j, cur);
+      if (!(M4Q_EXP & 32) && ok && lane_ok) {
+        for (int t0 = 0; t0 < T; t0 += 8) {
+          S buf[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) buf[q] = Xg.ld<S>((t0 + q + 1 <= T ? t0 + q + 1 : T) * NX + j);
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (t0 + q < T) Xg.st<S>((t0 + q) * NX + j, buf[q]);
         }
       }
       if (ok && jj < NU) {
-        for (int t = 0; t + 1 < T; ++t) Ug.st<double>(t * NU + jj, Ug.ld<double>((t + 1) * NU + jj));
+        for (int t0 = 0; t0 + 1 < T; t0 += 8) {
+          double buf[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) buf[q] = Ug.ld<double>((t0 + q + 1 < T ? t0 + q + 1 : T - 1) * NU + jj);
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (t0 + q + 1 < T) Ug.st<double>((t0 + q) * NU + jj, buf[q]);
+        }
       }
       if (ok) done_steps = step + 1;
       if (step_done) {
         iter = 0;
-        step = fail ? a.step_end : step + 1;
+        step = fail ? row_end : step + 1;
       }
-      __syncthreads();
+      wave_sync();
       if constexpr (PLANT == PLANT_NONE) {
         // the caller writes xs[step+1] before the next launch; inside one launch carry what is there
-        const bool carry = ok && step < a.step_end;
+        const bool carry = ok && step < row_end;
         const cplx xc = carry ? a.xs[b * sXs + (long)step * NX + j] : czero();
         const S rn = BasisIO<S>::template to_state<NX, DD>(xc, scratch, j, jj);
         if (carry) x_cur = rn;
       }
     }
 
-    // ---- rows that finished their run: publish the resumable state, free the slot ----
-    const bool finished = active && step >= a.step_end;
+    // ---- rows that finished their item: publish the resumable state, free the slot ----
+    const bool finished = active && step >= row_end;
     if (__any(finished)) {
+#pragma unroll 4
       for (int t = 0; t <= T; ++t) {
         const cplx xc = BasisIO<S>::template to_complex<NX, DD>(Xg.ld<S>(t * NX + j), scratch, j, jj);
         if (finished && lane_ok) a.Xg[b * sX + t * NX + j] = xc;
@@ -310,10 +376,22 @@ __global__ __launch_bounds__(64) M4Q_OCC void mpc_kernel(MpcArgs a) {
           a.codes[b] = code;
           a.steps_done[b] = done_steps;
         }
+      }
+      if (two_phase && __any(finished && row_end == 2)) {
+        // head item: make the state visible to whichever workgroup draws the tail (G16: stores drained,
+        // agent-scope release, drained again, then the flag)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_sync();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (finished && row_end == 2 && jj == 0)
+          __hip_atomic_store(a.head_done + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (finished) {
         active = false;
         need_new = true;
       }
-      __syncthreads();
+      wave_sync();
     }
   }
 }
@@ -332,9 +410,9 @@ __global__ __launch_bounds__(64) M4Q_OCC void linearize_kernel(LinArgs a) {
     const long q0 = (long)quad * ROWS;
     const bool valid = q0 + g < a.B;
     const unsigned gl = valid ? g : (unsigned)(a.B - 1 - q0);
-    __syncthreads();
+    wave_sync();
     stage_model(mdl, a.models + (q0 + gl) * a.model_stride, jj);
-    __syncthreads();
+    wave_sync();
     FusedProv<cplx, NX, NU, ORDER> prov;
     prov.mdl = mdl;
     prov.Xg = gview(a.X, q0 * sX, gl * sX);
@@ -392,7 +470,7 @@ __global__ __launch_bounds__(64) M4Q_OCC void qp_kernel(QpArgs a) {
     const GView Uo = gview(a.U_opt, q0 * sU, gl * sU);
     const bool st = valid && L.lane_ok;
     riccati_backward<cplx, NX, NU>(prov, T, win, cost, a.flags, gains, j, st);
-    __syncthreads();
+    wave_sync();
     double lo0[NU], hi0[NU], u_first[NU];
 #pragma unroll
     for (int k = 0; k < NU; ++k) {
@@ -405,7 +483,7 @@ __global__ __launch_bounds__(64) M4Q_OCC void qp_kernel(QpArgs a) {
     const double obj = rollout_forward<cplx, NX, NU, true>(prov, T, x0, win, cost, a.flags, gains, a.sat, lo0, hi0, Xo, Uo, j, st,
                                                               u_first);
     if (valid && jj == 0) a.cost[b] = obj;
-    __syncthreads();
+    wave_sync();
   }
 }
 

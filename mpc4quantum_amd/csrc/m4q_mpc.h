@@ -106,16 +106,16 @@ struct ModelPitch {
 //   a > b  : sqrt2 Im rho_ab   (antisymmetric part of the pair (b, a))
 // i.e. x = W r with x_ab = (r_ab - i r_ba)/sqrt2 (a < b), x_ab = (r_ba + i r_ab)/sqrt2 (a > b), x_aa = r_aa.
 // W is unitary; a Liouvillian-generated model, Hermitian states and Hermitian costs are all real in it.
-// Conversions go through a per-row LDS scratch of NX elements (one wave per workgroup: __syncthreads is
-// the wave's own LDS fence).
+// Conversions go through a per-row LDS scratch of NX elements (one wave per workgroup: wave_sync() orders
+// the exchange).
 // ---------------------------------------------------------------------------------------------
 template <int NX, int D>
 __device__ __forceinline__ cplx basis_to_complex(double r, double* sc, int j, int jj) {
   const int a = j / D, b = j - (j / D) * D;
   if (jj < NX) sc[jj] = r;
-  __syncthreads();
+  wave_sync();
   const double partner = sc[b * D + a];
-  __syncthreads();
+  wave_sync();
   const double rs = 0.70710678118654752440;
   if (a == b) return mk(r, 0.0);
   return a < b ? mk(r * rs, -partner * rs) : mk(partner * rs, r * rs);
@@ -124,9 +124,9 @@ template <int NX, int D>
 __device__ __forceinline__ double basis_to_real(cplx x, cplx* sc, int j, int jj) {
   const int a = j / D, b = j - (j / D) * D;
   if (jj < NX) sc[jj] = x;
-  __syncthreads();
+  wave_sync();
   const cplx partner = sc[b * D + a];
-  __syncthreads();
+  wave_sync();
   const double rs = 0.70710678118654752440;
   if (a == b) return x.re;
   return a < b ? (x.re + partner.re) * rs : (x.im - partner.im) * rs;
@@ -633,6 +633,7 @@ __device__ __forceinline__ void line_search_diag(const ZView<NX, NU>& z, const d
   if (jj < NX) {
     const int a = jj / D, b = jj - (jj / D) * D;
     const int partner = b * D + a;
+#pragma unroll 4
     for (int t = 0; t <= T; ++t) {
       const S g = z.Xg.template ld<S>(t * NX + jj), o = z.Xo.template ld<S>(t * NX + jj), tg = z.Xt.template ld<S>(t * NX + jj);
       const int q0 = jj * (T + 1) + t;          // Z slot of Re x_jj'; Im sits nxt further
@@ -817,17 +818,17 @@ __device__ __forceinline__ cplx plant_hamiltonian(cplx x, const double (&u)[NU],
     for (int a = 0; a < D; ++a) Us[a * D + jj] = G[a];
   }
   if (jj < NX) xs[jj] = x;
-  __syncthreads();
+  wave_sync();
   const int a = j / D, e = j - (j / D) * D;
   cplx m = czero();
 #pragma unroll
   for (int c = 0; c < D; ++c) cmac(m, Us[a * D + c], xs[c * D + e]);      // (U rho)[a][e]
   if (jj < NX) Ms[jj] = m;
-  __syncthreads();
+  wave_sync();
   cplx out = czero();
 #pragma unroll
   for (int c = 0; c < D; ++c) cmac_cj(out, Us[e * D + c], Ms[a * D + c]); // sum_c (U rho)[a][c] conj(U[e][c])
-  __syncthreads();
+  wave_sync();
   return out;
 }
 
