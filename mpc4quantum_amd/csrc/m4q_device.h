@@ -14,6 +14,7 @@
 // is wave-uniform and per-instance conditions are applied with selects.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <utility>
 
 namespace m4q {
@@ -173,134 +174,133 @@ template <class S> __device__ __forceinline__ S from_real(double r);
 template <> __device__ __forceinline__ double from_real<double>(double r) { return r; }
 template <> __device__ __forceinline__ cplx from_real<cplx>(double r) { return mk(r, 0.0); }
 
-// N-term statements, uniform over S (the conjugation flags are meaningless for double)
-template <bool CA, bool CB, int K0>
-__device__ __forceinline__ void macN(double& c0, double a0, double b0) { fmacN<K0>(c0, a0, b0); }
-template <bool CA, bool CB, int K0, int K1>
-__device__ __forceinline__ void macN(double& c0, double a0, double b0, double& c1, double a1, double b1) {
-  fmacN<K0, K1>(c0, a0, b0, c1, a1, b1);
+// ---- term emitter: a compile-time list of multiply-accumulate terms
+//        acc[IDX::acc(q)] += opA(lane_{IDX::lane(q)}(a[IDX::a(q)])) * opB(b[IDX::b(q)]),   q in [Q0, QN)
+// is cut into asm statements of up to 8 (double) / 4 (cplx) terms.  DOT: every term of the list adds into
+// acc[IDX::acc(Q0)] (dependent FMA chains are free on gfx950, so no partial sums); otherwise a statement
+// never holds two terms with the same accumulator (IDX::distinct = guaranteed run of distinct accumulators).
+template <class S> struct ChunkMax { static constexpr int value = 4; };
+template <> struct ChunkMax<double> { static constexpr int value = 8; };
+
+template <class IDX, bool CA, bool CB, bool DOT, int Q0, int NA, int NB, int NC, size_t... I>
+__device__ __forceinline__ void emit_block(double (&acc)[NA], const double (&a)[NB], const double (&b)[NC], std::index_sequence<I...>) {
+  if constexpr (DOT) fdotN<IDX::lane(Q0 + (int)I)...>(acc[IDX::acc(Q0)], a[IDX::a(Q0 + (int)I)]..., b[IDX::b(Q0 + (int)I)]...);
+  else fmacN<IDX::lane(Q0 + (int)I)...>(acc[IDX::acc(Q0 + (int)I)]..., a[IDX::a(Q0 + (int)I)]..., b[IDX::b(Q0 + (int)I)]...);
 }
-template <bool CA, bool CB, int K0, int K1, int K2>
-__device__ __forceinline__ void macN(double& c0, double a0, double b0, double& c1, double a1, double b1, double& c2, double a2,
-                                     double b2) {
-  fmacN<K0, K1, K2>(c0, a0, b0, c1, a1, b1, c2, a2, b2);
+template <class IDX, bool CA, bool CB, bool DOT, int Q0, int NA, int NB, int NC, size_t... I>
+__device__ __forceinline__ void emit_block(cplx (&acc)[NA], const cplx (&a)[NB], const cplx (&b)[NC], std::index_sequence<I...>) {
+  if constexpr (DOT) cdotN<CA, CB, IDX::lane(Q0 + (int)I)...>(acc[IDX::acc(Q0)], a[IDX::a(Q0 + (int)I)]..., b[IDX::b(Q0 + (int)I)]...);
+  else cmacN<CA, CB, IDX::lane(Q0 + (int)I)...>(acc[IDX::acc(Q0 + (int)I)]..., a[IDX::a(Q0 + (int)I)]..., b[IDX::b(Q0 + (int)I)]...);
 }
-template <bool CA, bool CB, int K0, int K1, int K2, int K3>
-__device__ __forceinline__ void macN(double& c0, double a0, double b0, double& c1, double a1, double b1, double& c2, double a2,
-                                     double b2, double& c3, double a3, double b3) {
-  fmacN<K0, K1, K2, K3>(c0, a0, b0, c1, a1, b1, c2, a2, b2, c3, a3, b3);
+template <class IDX, bool CA, bool CB, bool DOT, int Q0, int QN, class S, int NA, int NB, int NC>
+__device__ __forceinline__ void emit_terms(S (&acc)[NA], const S (&a)[NB], const S (&b)[NC]) {
+  constexpr int left = QN - Q0;
+  if constexpr (left > 0) {
+    constexpr int cap0 = ChunkMax<S>::value;
+    constexpr int cap = DOT ? cap0 : (cap0 < IDX::distinct ? cap0 : IDX::distinct);
+    constexpr int CH = left < cap ? left : cap;
+    emit_block<IDX, CA, CB, DOT, Q0>(acc, a, b, std::make_index_sequence<CH>{});
+    emit_terms<IDX, CA, CB, DOT, Q0 + CH, QN>(acc, a, b);
+  }
 }
-template <bool CA, bool CB, int K0>
-__device__ __forceinline__ void macN(cplx& c0, cplx a0, cplx b0) { cmacN<CA, CB, K0>(c0, a0, b0); }
-template <bool CA, bool CB, int K0, int K1>
-__device__ __forceinline__ void macN(cplx& c0, cplx a0, cplx b0, cplx& c1, cplx a1, cplx b1) {
-  cmacN<CA, CB, K0, K1>(c0, a0, b0, c1, a1, b1);
-}
-template <bool CA, bool CB, int K0, int K1, int K2>
-__device__ __forceinline__ void macN(cplx& c0, cplx a0, cplx b0, cplx& c1, cplx a1, cplx b1, cplx& c2, cplx a2, cplx b2) {
-  cmacN<CA, CB, K0, K1, K2>(c0, a0, b0, c1, a1, b1, c2, a2, b2);
-}
-template <bool CA, bool CB, int K0, int K1, int K2, int K3>
-__device__ __forceinline__ void macN(cplx& c0, cplx a0, cplx b0, cplx& c1, cplx a1, cplx b1, cplx& c2, cplx a2, cplx b2,
-                                     cplx& c3, cplx a3, cplx b3) {
-  cmacN<CA, CB, K0, K1, K2, K3>(c0, a0, b0, c1, a1, b1, c2, a2, b2, c3, a3, b3);
-}
+
+struct IdxLaneIndexScalar {   // acc[q] += lane_q(a[0]) * b[0]
+  static constexpr int distinct = 1 << 20;
+  static constexpr int acc(int q) { return q; }
+  static constexpr int a(int) { return 0; }
+  static constexpr int b(int) { return 0; }
+  static constexpr int lane(int q) { return q; }
+};
+struct IdxDotLane {           // acc[0] += lane_q(a[0]) * b[q]
+  static constexpr int distinct = 1;
+  static constexpr int acc(int) { return 0; }
+  static constexpr int a(int) { return 0; }
+  static constexpr int b(int q) { return q; }
+  static constexpr int lane(int q) { return q; }
+};
+struct IdxRowsum {            // acc[0] += lane_q(a[0]) * b[0]
+  static constexpr int distinct = 1;
+  static constexpr int acc(int) { return 0; }
+  static constexpr int a(int) { return 0; }
+  static constexpr int b(int) { return 0; }
+  static constexpr int lane(int q) { return q; }
+};
+template <int K>
+struct IdxSameLane {          // acc[q] += lane_K(a[q]) * b[0]
+  static constexpr int distinct = 1 << 20;
+  static constexpr int acc(int q) { return q; }
+  static constexpr int a(int q) { return q; }
+  static constexpr int b(int) { return 0; }
+  static constexpr int lane(int) { return K; }
+};
+template <int K>
+struct IdxSameLaneVec {       // acc[q] += lane_K(a[q]) * b[q]
+  static constexpr int distinct = 1 << 20;
+  static constexpr int acc(int q) { return q; }
+  static constexpr int a(int q) { return q; }
+  static constexpr int b(int q) { return q; }
+  static constexpr int lane(int) { return K; }
+};
+template <int N>
+struct IdxMatmul {            // C[i] += lane_k(M[i]) * B[k],   q = k*N + i
+  static constexpr int distinct = N;
+  static constexpr int acc(int q) { return q % N; }
+  static constexpr int a(int q) { return q % N; }
+  static constexpr int b(int q) { return q / N; }
+  static constexpr int lane(int q) { return q / N; }
+};
+template <int N>
+struct IdxMatmulHN {          // C[i] += conj(lane_i(M[k])) * B[k],   q = k*N + i
+  static constexpr int distinct = N;
+  static constexpr int acc(int q) { return q % N; }
+  static constexpr int a(int q) { return q / N; }
+  static constexpr int b(int q) { return q / N; }
+  static constexpr int lane(int q) { return q % N; }
+};
 
 // single-term conveniences
 template <int K, class S>
-__device__ __forceinline__ void cmac_bc(S& acc, S a, S b) { macN<false, false, K>(acc, a, b); }       // acc += lane_K(a) * b
-template <int K, class S>
-__device__ __forceinline__ void cmac_cjbc(S& acc, S a, S b) { macN<true, false, K>(acc, a, b); }      // acc += conj(lane_K(a)) * b
+__device__ __forceinline__ void cmac_bc(S& acc, S a, S b) {       // acc += lane_K(a) * b
+  S c1[1] = {acc};
+  const S a1[1] = {a}, b1[1] = {b};
+  emit_terms<IdxSameLane<K>, false, false, false, 0, 1>(c1, a1, b1);
+  acc = c1[0];
+}
 template <int K>
 __device__ __forceinline__ void fmac_bc(double& acc, double a, double b) { fmacN<K>(acc, a, b); }
 
-// acc[i] += opA(lane_K(a[i])) * opB(b)   for i in [I0, N): same lane, a chunk of up to four per statement
-template <bool CA, bool CB, int K, int I0, int N, class S>
+// acc[i] += opA(lane_K(a[i])) * opB(b)   for i in [0, N)
+template <bool CA, bool CB, int K, int N, class S>
 __device__ __forceinline__ void mac_same_lane(S (&acc)[N], const S (&a)[N], S b) {
-  if constexpr (N - I0 >= 4) {
-    macN<CA, CB, K, K, K, K>(acc[I0], a[I0], b, acc[I0 + 1], a[I0 + 1], b, acc[I0 + 2], a[I0 + 2], b, acc[I0 + 3], a[I0 + 3], b);
-    mac_same_lane<CA, CB, K, I0 + 4, N>(acc, a, b);
-  } else if constexpr (N - I0 == 3) {
-    macN<CA, CB, K, K, K>(acc[I0], a[I0], b, acc[I0 + 1], a[I0 + 1], b, acc[I0 + 2], a[I0 + 2], b);
-  } else if constexpr (N - I0 == 2) {
-    macN<CA, CB, K, K>(acc[I0], a[I0], b, acc[I0 + 1], a[I0 + 1], b);
-  } else if constexpr (N - I0 == 1) {
-    macN<CA, CB, K>(acc[I0], a[I0], b);
-  }
+  const S b1[1] = {b};
+  emit_terms<IdxSameLane<K>, CA, CB, false, 0, N>(acc, a, b1);
 }
-// acc[i] += opA(lane_K(a)) * opB(b[i])   same lane, same broadcast source, per-term own operand
-template <bool CA, bool CB, int K, int I0, int N, class S>
-__device__ __forceinline__ void mac_same_src(S (&acc)[N], S a, const S (&b)[N]) {
-  if constexpr (N - I0 >= 4) {
-    macN<CA, CB, K, K, K, K>(acc[I0], a, b[I0], acc[I0 + 1], a, b[I0 + 1], acc[I0 + 2], a, b[I0 + 2], acc[I0 + 3], a, b[I0 + 3]);
-    mac_same_src<CA, CB, K, I0 + 4, N>(acc, a, b);
-  } else if constexpr (N - I0 == 3) {
-    macN<CA, CB, K, K, K>(acc[I0], a, b[I0], acc[I0 + 1], a, b[I0 + 1], acc[I0 + 2], a, b[I0 + 2]);
-  } else if constexpr (N - I0 == 2) {
-    macN<CA, CB, K, K>(acc[I0], a, b[I0], acc[I0 + 1], a, b[I0 + 1]);
-  } else if constexpr (N - I0 == 1) {
-    macN<CA, CB, K>(acc[I0], a, b[I0]);
-  }
-}
-// acc[i] += opA(lane_i(a)) * opB(b)   for i in [I0, N): the broadcast lane is the row index
-template <bool CA, bool CB, int I0, int N, class S>
+// acc[i] += opA(lane_i(a)) * opB(b)   for i in [0, N): the broadcast lane is the row index
+template <bool CA, bool CB, int N, class S>
 __device__ __forceinline__ void mac_lane_index(S (&acc)[N], S a, S b) {
-  if constexpr (N - I0 >= 4) {
-    macN<CA, CB, I0, I0 + 1, I0 + 2, I0 + 3>(acc[I0], a, b, acc[I0 + 1], a, b, acc[I0 + 2], a, b, acc[I0 + 3], a, b);
-    mac_lane_index<CA, CB, I0 + 4, N>(acc, a, b);
-  } else if constexpr (N - I0 == 3) {
-    macN<CA, CB, I0, I0 + 1, I0 + 2>(acc[I0], a, b, acc[I0 + 1], a, b, acc[I0 + 2], a, b);
-  } else if constexpr (N - I0 == 2) {
-    macN<CA, CB, I0, I0 + 1>(acc[I0], a, b, acc[I0 + 1], a, b);
-  } else if constexpr (N - I0 == 1) {
-    macN<CA, CB, I0>(acc[I0], a, b);
-  }
+  const S a1[1] = {a}, b1[1] = {b};
+  emit_terms<IdxLaneIndexScalar, CA, CB, false, 0, N>(acc, a1, b1);
 }
-// part[c] += opA(lane_i(v)) * opB(m[i]) over i in [I0, N), four running partial sums
-template <bool CA, bool CB, int I0, int N, class S>
-__device__ __forceinline__ void dot_lane_index_acc(S (&part)[4], S v, const S (&m)[N]) {
-  if constexpr (N - I0 >= 4) {
-    macN<CA, CB, I0, I0 + 1, I0 + 2, I0 + 3>(part[0], v, m[I0], part[1], v, m[I0 + 1], part[2], v, m[I0 + 2], part[3], v, m[I0 + 3]);
-    dot_lane_index_acc<CA, CB, I0 + 4, N>(part, v, m);
-  } else if constexpr (N - I0 == 3) {
-    macN<CA, CB, I0, I0 + 1, I0 + 2>(part[0], v, m[I0], part[1], v, m[I0 + 1], part[2], v, m[I0 + 2]);
-  } else if constexpr (N - I0 == 2) {
-    macN<CA, CB, I0, I0 + 1>(part[0], v, m[I0], part[1], v, m[I0 + 1]);
-  } else if constexpr (N - I0 == 1) {
-    macN<CA, CB, I0>(part[0], v, m[I0]);
-  }
+// init + sum_i opA(lane_i(v)) * opB(m[i])
+template <bool CA, bool CB, int N, class S>
+__device__ __forceinline__ S dot_lane_index(S v, const S (&m)[N], S init) {
+  S c1[1] = {init};
+  const S a1[1] = {v};
+  emit_terms<IdxDotLane, CA, CB, true, 0, N>(c1, a1, m);
+  return c1[0];
 }
-// sum_i opA(lane_i(v)) * opB(m[i])
 template <bool CA, bool CB, int N, class S>
 __device__ __forceinline__ S dot_lane_index(S v, const S (&m)[N]) {
-  S part[4] = {zero_of<S>(), zero_of<S>(), zero_of<S>(), zero_of<S>()};
-  dot_lane_index_acc<CA, CB, 0, N>(part, v, m);
-  return cadd(cadd(part[0], part[1]), cadd(part[2], part[3]));
+  return dot_lane_index<CA, CB, N>(v, m, zero_of<S>());
 }
 
 // Sum over lanes 0..N-1 of the row; result replicated in every lane of the row.
-template <int I0, int N>
-__device__ __forceinline__ void rowsum_acc(double (&p)[8], double v, double one) {
-  if constexpr (N - I0 >= 8) {
-    fmacN<I0, I0 + 1, I0 + 2, I0 + 3, I0 + 4, I0 + 5, I0 + 6, I0 + 7>(p[0], v, one, p[1], v, one, p[2], v, one, p[3], v, one, p[4],
-                                                                      v, one, p[5], v, one, p[6], v, one, p[7], v, one);
-    rowsum_acc<I0 + 8, N>(p, v, one);
-  } else if constexpr (N - I0 >= 4) {
-    fmacN<I0, I0 + 1, I0 + 2, I0 + 3>(p[0], v, one, p[1], v, one, p[2], v, one, p[3], v, one);
-    rowsum_acc<I0 + 4, N>(p, v, one);
-  } else if constexpr (N - I0 == 3) {
-    fmacN<I0, I0 + 1, I0 + 2>(p[4], v, one, p[5], v, one, p[6], v, one);
-  } else if constexpr (N - I0 == 2) {
-    fmacN<I0, I0 + 1>(p[4], v, one, p[5], v, one);
-  } else if constexpr (N - I0 == 1) {
-    fmacN<I0>(p[4], v, one);
-  }
-}
 template <int N>
 __device__ __forceinline__ double rowsum(double v) {
-  double p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  rowsum_acc<0, N>(p, v, 1.0);
-  return ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+  double c1[1] = {0.0};
+  const double a1[1] = {v}, b1[1] = {1.0};
+  emit_terms<IdxRowsum, false, false, true, 0, N>(c1, a1, b1);
+  return c1[0];
 }
 template <int N>
 __device__ __forceinline__ cplx rowsum(cplx v) {
@@ -318,17 +318,13 @@ template <int N, class S>
 __device__ __forceinline__ void matmul_cols(S (&C)[N], const S (&M)[N], const S (&Bc)[N]) {
 #pragma unroll
   for (int i = 0; i < N; ++i) C[i] = zero_of<S>();
-  static_for<0, N>([&](auto kk) {
-    constexpr int k = decltype(kk)::value;
-    mac_same_lane<false, false, k, 0, N>(C, M, Bc[k]);
-  });
+  emit_terms<IdxMatmul<N>, false, false, false, 0, N * N>(C, M, Bc);
 }
 
 // C[:, j] += M^H * B[:, j]   with M, B column-owned:  C[i] += conj(lane_i(M[k])) * B[k]
 template <int N, class S>
 __device__ __forceinline__ void matmul_cols_hn_acc(S (&C)[N], const S (&M)[N], const S (&Bc)[N]) {
-#pragma unroll
-  for (int k = 0; k < N; ++k) mac_lane_index<true, false, 0, N>(C, M[k], Bc[k]);
+  emit_terms<IdxMatmulHN<N>, true, false, false, 0, N * N>(C, M, Bc);
 }
 
 // y_j = sum_i conj(M[i][j]) v_i  with M column-owned, v distributed  (= (M^H v)_j; = (M v)_j if M Hermitian)

@@ -188,28 +188,43 @@ struct FusedProv {
     Poly<NU, ORDER> po;
     po.eval(l.u);
     S nx[NP];
+    if constexpr (sizeof(S) == sizeof(double)) {
+      // real path: whole rows in registers, one long dot per accumulator (8 FMAs per statement)
+      //   av = sum_k lane_k(v) A_t[j][k],   nx[p] = sum_k lane_k(xg) N_p[j][k]
+      S arow[NX];
 #pragma unroll
-    for (int p = 0; p < NP; ++p) nx[p] = zero_of<S>();
-    av = zero_of<S>();
-    static_for<0, NX>([&](auto kk) {
-      constexpr int k = decltype(kk)::value;
-      S a = mdl[j * PITCH + k];
-      S np[NP];
+      for (int k = 0; k < NX; ++k) arow[k] = mdl[j * PITCH + k];
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        np[p] = mdl[((1 + p) * NX + j) * PITCH + k];
-        cmac_r(a, np[p], po.pu[p]);
+        S nrow[NX];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+          nrow[k] = mdl[((1 + p) * NX + j) * PITCH + k];
+          cmac_r(arow[k], nrow[k], po.pu[p]);
+        }
+        nx[p] = dot_lane_index<false, false, NX>(l.xg, nrow);
       }
-      if constexpr (NP <= 3) {
-        // one statement: nx[p] += lane_k(xg) * N_p[j][k] for every p, and av += lane_k(v) * A_t[j][k]
-        if constexpr (NP == 1) macN<false, false, k, k>(nx[0], l.xg, np[0], av, v, a);
-        else if constexpr (NP == 2) macN<false, false, k, k, k>(nx[0], l.xg, np[0], nx[1], l.xg, np[1], av, v, a);
-        else macN<false, false, k, k, k, k>(nx[0], l.xg, np[0], nx[1], l.xg, np[1], nx[2], l.xg, np[2], av, v, a);
-      } else {
-        mac_same_src<false, false, k, 0, NP>(nx, l.xg, np);
-        macN<false, false, k>(av, v, a);
-      }
-    });
+      av = dot_lane_index<false, false, NX>(v, arow);
+    } else {
+      // complex path (register bound): one statement per column k with the NP+1 accumulators
+      S accs[NP + 1], srcs[NP + 1];
+#pragma unroll
+      for (int p = 0; p <= NP; ++p) { accs[p] = zero_of<S>(); srcs[p] = p < NP ? l.xg : v; }
+      static_for<0, NX>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        S own[NP + 1];
+        own[NP] = mdl[j * PITCH + k];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          own[p] = mdl[((1 + p) * NX + j) * PITCH + k];
+          cmac_r(own[NP], own[p], po.pu[p]);
+        }
+        emit_terms<IdxSameLaneVec<k>, false, false, false, 0, NP + 1>(accs, srcs, own);
+      });
+#pragma unroll
+      for (int p = 0; p < NP; ++p) nx[p] = accs[p];
+      av = accs[NP];
+    }
     dlt = zero_of<S>();
 #pragma unroll
     for (int k = 0; k < NU; ++k) {
@@ -333,12 +348,8 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
     // BhP[k] = (B^H P)[k][j] = sum_i conj(B[i][k]) P[i][j]
     S BhP[NU];
 #pragma unroll
-    for (int k = 0; k < NU; ++k) BhP[k] = zero_of<S>();
-    static_for<0, NX>([&](auto ii) {
-      constexpr int i = decltype(ii)::value;
-      mac_same_lane<true, false, i, 0, NU>(BhP, Brow, Pc[i]);
-    });
-    const S w = cadd(matvec_h<NX>(Pc, c), pv);                // (P c + p)_j
+    for (int k = 0; k < NU; ++k) BhP[k] = dot_lane_index<true, false, NX>(Brow[k], Pc);
+    const S w = dot_lane_index<false, true, NX>(c, Pc, pv);   // (P c + p)_j
 
     // G = R + B^H P B (replicated), h = B^H (P c + p)
     const S* Rt = cost.r(t);
@@ -361,11 +372,7 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
     // Hh[l] = (B^H P A_t)[l][j] = sum_i BhP[l][i] A_t[i][j]
     S Hh[NU];
 #pragma unroll
-    for (int l = 0; l < NU; ++l) Hh[l] = zero_of<S>();
-    static_for<0, NX>([&](auto ii) {
-      constexpr int i = decltype(ii)::value;
-      mac_same_lane<false, false, i, 0, NU>(Hh, BhP, Ac[i]);
-    });
+    for (int l = 0; l < NU; ++l) Hh[l] = dot_lane_index<false, false, NX>(BhP[l], Ac);
     S Kx[NU], kk[NU];
 #pragma unroll
     for (int k = 0; k < NU; ++k) {
@@ -390,7 +397,7 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
 
     // closed loop: Sx = A_t + B Kx (column j, in place): Ac[i] += lane_i(B[i][k]) Kx[k];  s = c + B k
 #pragma unroll
-    for (int k = 0; k < NU; ++k) mac_lane_index<false, false, 0, NX>(Ac, Brow[k], Kx[k]);
+    for (int k = 0; k < NU; ++k) mac_lane_index<false, false, NX>(Ac, Brow[k], Kx[k]);
     S s = c;
 #pragma unroll
     for (int k = 0; k < NU; ++k) cmac(s, Brow[k], kk[k]);
@@ -398,7 +405,7 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
 
     S PSc[NX];
     matmul_cols<NX>(PSc, Pc, Ac);                              // P Sx
-    const S ws = cadd(matvec_h<NX>(Pc, s), pv);               // (P s + p)_j
+    const S ws = dot_lane_index<false, true, NX>(s, Pc, pv);  // (P s + p)_j
     M4Q_PHASE();
 
     S RK[NU], Rk[NU];
@@ -419,7 +426,7 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
     for (int i = 0; i < NX; ++i) Pn[i] = Qt[i * NX + j];
     matmul_cols_hn_acc<NX>(Pn, Ac, PSc);                       // + Sx^H P Sx
 #pragma unroll
-    for (int k = 0; k < NU; ++k) mac_lane_index<true, false, 0, NX>(Pn, Kx[k], RK[k]);   // + Kx^H R Kx
+    for (int k = 0; k < NU; ++k) mac_lane_index<true, false, NX>(Pn, Kx[k], RK[k]);   // + Kx^H R Kx
     S pn = matvec_h<NX>(Ac, ws);                               // Sx^H (P s + p)
 #pragma unroll
     for (int k = 0; k < NU; ++k) cmac_cj(pn, Kx[k], Rk[k]);
