@@ -25,8 +25,8 @@ struct MpcArgs {
   const cplx* ops; long ops_stride;
   cplx* xs; double* us; int* codes; int* steps_done; int* qp_solves;
   cplx* Xg; double* Ug;                     // per-instance SQP guess  [B][T+1][n] complex, [B][T][m] (resumable state)
-  // per resident row (grid*4 of them): working guess, QP solution, gains (S)
-  void* ws_Xg; double* ws_Ug; void* ws_Xo; double* ws_Uo; void* ws_gains;
+  // per resident row (grid*4 of them): working guess followed by the QP solution (S [2][rows][T+1][n], [2][rows][T][m]), gains (S)
+  void* ws_Xg; double* ws_Ug; void* ws_gains;
   int* queue;                               // next work item to hand out; zeroed before every launch
   int* head_done;                           // [B] set when an instance's head item (steps < 2) has been published; zeroed likewise
 };

@@ -166,7 +166,7 @@ struct m4q_session {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int grid = 1;
   DevBuf f[M4Q_F_COUNT];
-  DevBuf Cq, Cqf, Cr, Wls, wsXg, wsUg, wsXo, wsUo, wsG, queue, head_done;
+  DevBuf Cq, Cqf, Cr, Wls, wsXg, wsUg, wsG, queue, head_done;
   size_t fbytes[M4Q_F_COUNT]{};
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
   double ms_total = 0.0;
@@ -276,12 +276,10 @@ int m4q_session_create(const m4q_problem* p, int32_t B, int32_t device, m4q_sess
   long resident = (long)per_cu * prop.multiProcessorCount;
   s->grid = (int)(nquads < resident ? nquads : resident);
   const size_t rows = (size_t)s->grid * 4;
-  if (!rc) rc = s->wsXg.alloc(rows * (T + 1) * n * C);
-  if (!rc) rc = s->wsUg.alloc(rows * T * m * 8);
+  if (!rc) rc = s->wsXg.alloc(2 * rows * (T + 1) * n * C);      // [Xg rows][Xo rows]
+  if (!rc) rc = s->wsUg.alloc(2 * rows * T * m * 8);            // [Ug rows][Uo rows]
   if (!rc) rc = s->queue.alloc(64);
   if (!rc) rc = s->head_done.alloc((size_t)B * 4);
-  if (!rc) rc = s->wsXo.alloc(rows * (T + 1) * n * C);
-  if (!rc) rc = s->wsUo.alloc(rows * T * m * 8);
   if (!rc) rc = s->wsG.alloc(rows * T * (n + 1) * m * C);
   if (!rc) rc = s->Cq.alloc(4 * n * n * 8);
   if (!rc) rc = s->Cqf.alloc(4 * n * n * 8);
@@ -486,7 +484,7 @@ int m4q_session_run(m4q_session* s, int32_t step_begin, int32_t step_end) {
   a.codes = (int*)s->f[M4Q_F_CODES].p; a.steps_done = (int*)s->f[M4Q_F_STEPS_DONE].p; a.qp_solves = (int*)s->f[M4Q_F_QP_SOLVES].p;
   a.Xg = (cplx*)s->f[M4Q_F_X_GUESS].p; a.Ug = (double*)s->f[M4Q_F_U_GUESS].p;
   a.ws_Xg = s->wsXg.p; a.ws_Ug = (double*)s->wsUg.p;
-  a.ws_Xo = s->wsXo.p; a.ws_Uo = (double*)s->wsUo.p; a.ws_gains = s->wsG.p;
+  a.ws_gains = s->wsG.p;
   a.queue = (int*)s->queue.p;
   a.head_done = (int*)s->head_done.p;
   HIP_TRY(hipMemsetAsync(s->queue.p, 0, 64, s->stream));
@@ -543,7 +541,7 @@ int m4q_session_info(const m4q_session* s, int64_t* hbm_bytes, int32_t* grid, in
   if (!s) return fail(M4Q_E_BADARG, "m4q_session_info: null session");
   int64_t tot = 0;
   for (int i = 0; i < M4Q_F_COUNT; ++i) tot += (int64_t)s->f[i].bytes;
-  tot += (int64_t)(s->wsXg.bytes + s->wsUg.bytes + s->wsXo.bytes + s->wsUo.bytes + s->wsG.bytes);
+  tot += (int64_t)(s->wsXg.bytes + s->wsUg.bytes + s->wsG.bytes);
   if (hbm_bytes) *hbm_bytes = tot;
   if (grid) *grid = s->grid;
   if (lds_bytes) *lds_bytes = (int32_t)s->shape->mpc_lds_bytes(s->use_real() ? 1 : 0);

@@ -128,8 +128,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
   const unsigned sX = (unsigned)(T + 1) * NX, sU = (unsigned)T * NU, sG = (unsigned)T * (NX + 1) * NU;
   const GView Xg = gview(static_cast<S*>(a.ws_Xg), (long)blockIdx.x * ROWS * sX, g * sX);
   const GView Ug = gview(a.ws_Ug, (long)blockIdx.x * ROWS * sU, g * sU);
-  const GView Xo = gview(static_cast<S*>(a.ws_Xo), (long)blockIdx.x * ROWS * sX, g * sX);
-  const GView Uo = gview(a.ws_Uo, (long)blockIdx.x * ROWS * sU, g * sU);
+  // (Xo, Uo) live in the same allocations right behind all the (Xg, Ug): same wave-uniform base, so a row can
+  // direct its rollout output to either by its lane offset alone
+  const GView Xo = gview(static_cast<S*>(a.ws_Xg), (long)blockIdx.x * ROWS * sX, g * sX + gridDim.x * ROWS * sX);
+  const GView Uo = gview(a.ws_Ug, (long)blockIdx.x * ROWS * sU, g * sU + gridDim.x * ROWS * sU);
   const GView gains = gview(static_cast<S*>(a.ws_gains), (long)blockIdx.x * ROWS * sG, g * sG);
   FusedProv<S, NX, NU, ORDER> prov;
   prov.mdl = mdl; prov.Xg = Xg; prov.Ug = Ug; prov.j = j;
@@ -264,7 +266,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
     for (int k = 0; k < NU; ++k) uapp[k] = 0.0;
     double chk = 0.0;
     if constexpr (!(M4Q_EXP & 4))
-      chk = rollout_forward<S, NX, NU, false>(prov, T, x_cur, win, cost, a.flags, gains, a.sat, lo0, hi0, Xo, Uo, j, st, uapp);
+      chk = rollout_forward<S, NX, NU, false>(prov, T, x_cur, win, cost, a.flags, gains, a.sat, lo0, hi0, Xo, Uo, j, st, uapp,
+                                              !use_ls, &Xg, &Ug);
     wave_sync();
     const bool fail = !finite_d(chk);                      // mpc.py:200-203
     if (running) ++iter;
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
     }
     if (M4Q_EXP & 1) { fin = !use_ls || iter >= 3; alpha = 1.0; }
     wave_sync();
-    const bool upd = running && !fail;
+    const bool upd = running && !fail && use_ls;      // warm steps wrote the shifted guess in the rollout
     // X_guess += alpha (X_opt - X_guess) (mpc.py:228-229)
     // (these small per-element passes are latency bound: unrolled so that several loads are in flight)
     if (!(M4Q_EXP & 16) && upd && lane_ok) {
@@ -327,7 +330,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
         if (ok && lane_ok) a.xs[b * sXs + (long)(step + 1) * NX + j] = xn;
       }
       // shift_guess (mpc.py:71-73,271-272): drop column 0, repeat the last
-      if (!(M4Q_EXP & 32) && ok && lane_ok) {
+      const bool shift_now = ok && use_ls;          // (a warm step's rollout has already shifted)
+      if (!(M4Q_EXP & 32) && shift_now && lane_ok) {
         for (int t0 = 0; t0 < T; t0 += 8) {
           S buf[8];
 #pragma unroll
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
             if (t0 + q < T) Xg.st<S>((t0 + q) * NX + j, buf[q]);
         }
       }
-      if (ok && jj < NU) {
+      if (shift_now && jj < NU) {
         for (int t0 = 0; t0 + 1 < T; t0 += 8) {
           double buf[8];
 #pragma unroll

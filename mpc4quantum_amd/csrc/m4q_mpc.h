@@ -449,15 +449,29 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
 // x distributed (lane j holds x_t[j]).  WANT_COST: return the objective (replicated over the row);
 // otherwise return sum |x|^2 + sum u^2, which is finite exactly when every state and control is -
 // all the closed loop needs for its exit code 3 (mpc.py:200-203).  u_first receives the first control.
+// shift_out (per row): the solution goes straight into the NEXT step's guess - Xg/Ug, already shifted as
+// mpc.py:271-272 does (x_{t+1} -> Xg[t], u_t -> Ug[t-1], last column repeated) - which is what a warm
+// step (alpha = 1, mpc.py:208-212) ends up with after its update and shift passes.  Safe in place: index
+// t of the guess has been read (one iteration ahead) before it is overwritten.
 // ---------------------------------------------------------------------------------------------
 template <class S, int NX, int NU, bool WANT_COST, class Prov>
 __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0, const Window& win, const CostRef<S>& cost,
                                                    int flags, const GView& gains, double sat, const double (&lo0)[NU],
                                                    const double (&hi0)[NU], const GView& Xo, const GView& Uo, int j,
-                                                   bool store_ok, double (&u_first)[NU]) {
+                                                   bool store_ok, double (&u_first)[NU], bool shift_out = false,
+                                                   const GView* Xg = nullptr, const GView* Ug = nullptr) {
   const bool ref = (flags & QP_REF_LQR) != 0;
   S x = x0;
-  if (store_ok) Xo.st<S>(j, x);
+  // destination views: lane offsets select between (Xo, Uo) and the shifted guess
+  GView Xd = Xo, Ud = Uo;
+  int xs_shift = 1, us_shift = 0;
+  if (Xg != nullptr) {
+    Xd.off = shift_out ? Xg->off : Xo.off;
+    Ud.off = shift_out ? Ug->off : Uo.off;
+    xs_shift = shift_out ? 0 : 1;
+    us_shift = shift_out ? -1 : 0;
+  }
+  if (store_ok && !shift_out) Xd.st<S>(j, x);
   double cx = 0.0;     // per-lane share of the state cost
   double cu = 0.0;     // control cost (replicated)
   struct Ops {
@@ -526,10 +540,17 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
     }
     x = xn;
     if (store_ok) {
-      Xo.st<S>((t + 1) * NX + j, x);
-      if (j == 0) {
+      Xd.st<S>((t + xs_shift) * NX + j, x);
+      if (j == 0 && t + us_shift >= 0) {
 #pragma unroll
-        for (int k = 0; k < NU; ++k) Uo.st<double>(t * NU + k, u[k]);
+        for (int k = 0; k < NU; ++k) Ud.st<double>((t + us_shift) * NU + k, u[k]);
+      }
+      if (shift_out && t == T - 1) {
+        Xd.st<S>(T * NX + j, x);                       // repeat the last column
+        if (j == 0) {
+#pragma unroll
+          for (int k = 0; k < NU; ++k) Ud.st<double>((T - 1) * NU + k, u[k]);
+        }
       }
     }
     cur = nxt;
