@@ -24,7 +24,8 @@ sys.path.insert(0, ROOT)
 
 # algorithmic work per horizon-step (SURVEY.md 8d / BASELINE.md 4), order 1
 ALG_FLOP = {4: 3.5e3, 9: 27e3, 16: 126e3}
-PEAK_F64_TFLOPS = 78.6      # MI355X fp64 vector == fp64 matrix dense rate (AMD spec; 256 CU x 4 SIMD x 16 FMA lanes x 2.4 GHz)
+PEAK_F64_TFLOPS = 78.6      # MI355X fp64 vector == fp64 matrix dense rate (AMD spec; 256 CU x 4 SIMD x 16 FMA lanes x 2.4 GHz;
+                            # tools/ubench_dpp.hip measures 78.0 with v_fmac_f64_dpp)
 PEAK_HBM_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -38,17 +39,23 @@ def cpu_baseline(p, seconds_budget=20.0):
     of the same ensemble until ~seconds_budget is spent."""
     from oracle import m4q_oracle as orc
     import numpy as np
-    t0 = time.perf_counter()
     units = 0
     done = 0
-    while done < p["x0"].shape[0] and (time.perf_counter() - t0 < seconds_budget or done < 2):
-        mdl = p["models"][done:done + 1] if p["models"].shape[0] > 1 else p["models"]
+    spent = 0.0
+    while done < p["x0"].shape[0] and (spent < seconds_budget or done < 2):
+        if p["scales"] is not None:      # the member's model, built outside the timed part (setup, not the hot path)
+            gens = [p["scales"][done, k] * p["generators"][k] for k in range(p["generators"].shape[0])]
+            mdl = orc.discretize_homogeneous(gens, p["dt"], p["order"])[None]
+        else:
+            mdl = orc.discretize_homogeneous(list(p["generators"]), p["dt"], p["order"])[None]
+        t0 = time.perf_counter()
         _, _, _, solves = orc.mpc_batch(p["x0"][done:done + 1], mdl, p["dim_u"], p["order"], p["X_targ"], p["U_targ"], p["dt"],
                                         p["horizon"], p["n_steps"], p["plant_op0"], list(p["plant_ops"][0]), p["Q"], p["R"],
                                         p["Qf"], p["sat"], p["du"])
+        spent += time.perf_counter() - t0
         units += int(solves.sum()) * p["horizon"]
         done += 1
-    dt = time.perf_counter() - t0
+    dt = spent
     return {"value": units / dt, "unit": "MPC horizon-steps/s", "cores": 1, "kind": "port",
             "sample": "first %d of %d ensemble members, full closed loop (n_steps=%d, T=%d), NumPy oracle, %.1f s"
                       % (done, p["x0"].shape[0], p["n_steps"], p["horizon"], dt)}
@@ -80,19 +87,15 @@ def main():
     from mpc4quantum_amd import _lib, configs
     from mpc4quantum_amd.session import EnsembleSession
 
-    p = configs.build(args.config, batch=args.batch)
-    # each rank takes its own slice of a world-sized ensemble: different seeds per rank would change the
-    # workload; the config's generator is deterministic, so ranks differ by an index offset into a larger draw
-    if world > 1:
-        big = configs.build(args.config, batch=p["batch"] * world)
-        sl = slice(rank * p["batch"], (rank + 1) * p["batch"])
-        p["x0"] = np.ascontiguousarray(big["x0"][sl])
-        if big["models"].shape[0] > 1:
-            p["models"] = np.ascontiguousarray(big["models"][sl])
+    # every rank takes its own slice [rank*B, (rank+1)*B) of ONE world-sized ensemble draw (weak scaling);
+    # per-member models are built on the device from the config's generators and scales
+    full = args.batch or {1: 1, 2: 8192, 3: 65536, 4: 65536, 5: 2 ** 20}[args.config]
+    p = configs.build(args.config, batch=full, offset=rank * full, total=full * world, host_models=False)
     B, n, m, T, ns = p["batch"], p["dim_x"], p["dim_u"], p["horizon"], p["n_steps"]
-    P = p["models"].shape[2] // n - 1
+    P = _lib.lib().m4q_library_size(p["order"], m)
+    per_model = p["scales"] is not None
 
-    sess = EnsembleSession(B, n, m, p["order"], T, ns, p["dt"], p["sat"], p["du"], model_per_instance=p["models"].shape[0] > 1,
+    sess = EnsembleSession(B, n, m, p["order"], T, ns, p["dt"], p["sat"], p["du"], model_per_instance=per_model,
                            target_cols=ns + T + 1, device=local_rank if world > 1 else -1)
     gather_bufs = None
     if world > 1:
@@ -103,7 +106,13 @@ def main():
         sess.bind_output(_lib.F_XS, xs_t.data_ptr(), xs_t.numel() * 8)
         us_all = torch.empty(world * us_t.numel(), dtype=torch.float64, device="cuda") if rank == 0 else None
         gather_bufs = (us_t, us_all)
-    sess.load_problem(p["models"], p["x0"], p["X_targ"], p["U_targ"], p["Q"], p["R"], p["Qf"], p["plant_op0"], p["plant_ops"])
+    if per_model:
+        sess.build_models(p["dt"], p["generators"], p["scales"])
+        models = None
+    else:
+        models = p["models"] if p["models"] is not None else configs.build(args.config, batch=1)["models"]
+    sess.load_problem(models, p["x0"], p["X_targ"], p["U_targ"], p["Q"], p["R"], p["Qf"], p["plant_op0"], p["plant_ops"])
+    path = sess.path()
 
     def one_step():
         sess.run(0, ns)
@@ -167,15 +176,15 @@ def main():
                       else "MPC horizon-steps/sec across batch (config %d)" % args.config,
             "value": value, "unit": "MPC horizon-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64" if path == "real" else "c128", "data": "synthetic",
             "config": {"workload": "BASELINE config %d: d=%d (n=%d, m=%d), order %d, T=%d, n_steps=%d, %d ensemble members per GPU, "
-                                   "per-instance models, full closed loop per step" % (args.config, p["d"], n, m, p["order"], T, ns, B),
+                                   "per-instance models, full closed loop per step; %s arithmetic path" % (args.config, p["d"], n, m, p["order"], T, ns, B, path),
                        "batch_per_gpu": B, "horizon": T, "n_steps": ns, "qp_solves_per_step": units_per_step // T,
                        "instances_ok": ok_total, "parallelism": "ensemble-sharded x%d, one gather" % world,
                        "grid": info["grid"], "lds_bytes": info["lds_bytes"], "hbm_resident_bytes": info["hbm_bytes"]},
             "roofline": {"bound": "mfma", "achieved": flops / avg_launch_s / 1e12, "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s",
                          "frac": flops / avg_launch_s / 1e12 / PEAK_F64_TFLOPS, "traffic": traffic,
-                         "kernel": "mpc_kernel<PLANT_HAMILTONIAN>", "launches": launches, "avg_launch_ms": 1e3 * avg_launch_s,
+                         "kernel": "mpc_kernel<%s, PLANT_HAMILTONIAN>" % ("double" if path == "real" else "cplx"), "launches": launches, "avg_launch_ms": 1e3 * avg_launch_s,
                          "note": "fp64 compute roof: v_fma_f64 (VALU, used here with DPP row broadcasts) and v_mfma_f64 share the "
                                  "78.6 TFLOP/s dense rate on MI355X; algorithmic flops = 27 kflop/horizon-step (SURVEY 8d)",
                          "hbm": {"achieved": abytes / avg_launch_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",

@@ -113,6 +113,12 @@ M4Q_API int m4q_quad_program_batch(int32_t B, int32_t dim_x, int32_t dim_u, int3
                            const double* Delta_ls, const double* u_prev, double* X_opt, double* U_opt, double* cost,
                            double* gains);
 
+/* replaces vectorize.discretize_homogeneous (vectorize.py:8-49) for B operator sets: the Taylor/Dyson expansion of
+ * exp(dt (G_0 + sum_k u_k G_k)) to `order`, binned by control monomial.
+ * generators [B|1][1+m][n][n] c, scaled per member by scales [B][1+m] r when given (NULL = 1) -> models [B][n][n(1+P)] c */
+M4Q_API int m4q_discretize_batch(int32_t B, int32_t dim_x, int32_t dim_u, int32_t order, double dt, const double* generators,
+                         int32_t gen_per_instance, const double* scales, double* models);
+
 /* replaces QExperiment.simulate over one held-control step (experiment.py:202-212, mpc.py:256-260).
  * x [B][n] c, u [B][m] r, op0 [B|1][k][k] c, ops [B|1][m][k][k] c with k = d (HAMILTONIAN) or n (GENERATOR)
  * -> x_next [B][n] c */
@@ -163,6 +169,10 @@ M4Q_API int m4q_session_download(m4q_session* s, int32_t field, void* host, size
 /* upload/download one MPC step's column of XS for every instance: host [B][n] c (host plants) */
 M4Q_API int m4q_session_put_state(m4q_session* s, int32_t step, const void* host);
 M4Q_API int m4q_session_get_state(m4q_session* s, int32_t step, void* host);
+/* fill M4Q_F_MODELS on the device from continuous-time generators (as m4q_discretize_batch; dt, generators
+ * [B|1][1+m][n][n] c and scales [B][1+m] r (or NULL) are host buffers): no model ever crosses PCIe */
+M4Q_API int m4q_session_build_models(m4q_session* s, double dt, const double* generators, int32_t gen_per_instance,
+                             const double* scales);
 /* raw device pointer of a field (for collectives on the results); NULL if unknown */
 M4Q_API void* m4q_session_device_ptr(m4q_session* s, int32_t field);
 /* use caller-owned DEVICE memory for an output field (XS, US, CODES, STEPS_DONE, QP_SOLVES) */

@@ -10,6 +10,6 @@ from .model import DMDc  # noqa: F401
 from .mpc import StepClock, iqp_line_search, mpc, mpc_batch, shift_guess, val_to_str  # noqa: F401
 from .optimize import quad_program, quad_program_batch  # noqa: F401
 from .session import EnsembleSession  # noqa: F401
-from .vectorize import discretize_homogeneous, liouvillian, vectorize_me  # noqa: F401
+from .vectorize import discretize_homogeneous, discretize_homogeneous_batch, liouvillian, vectorize_me  # noqa: F401
 
 __version__ = "0.1.0"

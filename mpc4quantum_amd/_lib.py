@@ -51,6 +51,8 @@ PROTOTYPES = {
     "m4q_linearize_batch": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _dp, _i32, _dp, _dp, _dp, _dp, _dp]),
     "m4q_quad_program_batch": (C.c_int, [_i32, _i32, _i32, _i32, _i32, C.c_double, C.c_double, _dp, _dp, _dp, _i32,
                                          _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "m4q_discretize_batch": (C.c_int, [_i32, _i32, _i32, _i32, C.c_double, _dp, _i32, _dp, _dp]),
+    "m4q_session_build_models": (C.c_int, [_vp, C.c_double, _dp, _i32, _dp]),
     "m4q_plant_step_batch": (C.c_int, [_i32, _i32, _i32, _i32, C.c_double, _dp, _dp, _dp, _dp, _i32, _dp]),
     "m4q_mpc_batch": (C.c_int, [C.POINTER(Problem), _i32, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip,
                                 _ip, _ip]),

@@ -29,9 +29,12 @@ def _targets(target_state, n_steps, horizon, dim_u):
     return X, U
 
 
-def build(config, batch=None, order=1, horizon=None, n_steps=None):
+def build(config, batch=None, order=1, horizon=None, n_steps=None, offset=0, total=None, host_models=True):
     """Returns a dict with: name, dim_x, dim_u, order, dt, horizon, n_steps, sat, du, Q, R, Qf, x0 [B,n],
-    models [B|1,n,n(1+P)], X_targ (n,cols), U_targ (m,cols-1), plant_op0 [1|B,d,d], plant_ops [1|B,m,d,d]."""
+    models [B|1,n,n(1+P)], X_targ (n,cols), U_targ (m,cols-1), plant_op0 [1|B,d,d], plant_ops [1|B,m,d,d],
+    generators [1+m,n,n] and scales [B,1+m] (the continuous-time operators the models come from; models is None when
+    host_models=False: build them on the device).  (offset, total): this call returns members [offset, offset+batch)
+    of a `total`-member draw, so ranks of a sharded run see disjoint slices of ONE ensemble."""
     config = int(config)
     if config in (1, 2):
         d, m = 2, 1
@@ -57,7 +60,16 @@ def build(config, batch=None, order=1, horizon=None, n_steps=None):
             psi = rng.standard_normal((B, 2)) + 1j * rng.standard_normal((B, 2))
             psi /= np.linalg.norm(psi, axis=1, keepdims=True)
             x0 = np.einsum('bi,bj->bij', psi, psi.conj()).reshape(B, -1)
-        models = discretize_homogeneous([liouvillian(h) for h in H_model], dt, order)[None]
+        gens = np.stack([liouvillian(h) for h in H_model])
+        scales = None
+        if config == 2:
+            rng = np.random.default_rng(2)
+            tot = total or B
+            psi = rng.standard_normal((tot, 2)) + 1j * rng.standard_normal((tot, 2))
+            psi = psi[offset:offset + B]
+            psi /= np.linalg.norm(psi, axis=1, keepdims=True)
+            x0 = np.einsum('bi,bj->bij', psi, psi.conj()).reshape(B, -1)
+        models = discretize_homogeneous(list(gens), dt, order)[None]
         plant0, plantk = H_plant0[None], np.stack([H_model[1]])[None]
     elif config in (3, 5):
         d, m = 3, 2
@@ -81,14 +93,14 @@ def build(config, batch=None, order=1, horizon=None, n_steps=None):
         x0 = np.tile(rho0.reshape(1, -1), (B, 1))
         target = _proj(3, 1).reshape(-1)
         rng = np.random.default_rng(3 if config == 3 else 5)
-        xi = rng.standard_normal(B)
-        zeta = rng.standard_normal(B)
-        alphas = alpha0 * (1 + 0.05 * xi)
-        scale = 1 + 0.02 * zeta
-        L0 = alphas[:, None, None] * liouvillian(P2)[None]
-        LX = scale[:, None, None] * liouvillian(HX)[None]
-        LY = scale[:, None, None] * liouvillian(HY)[None]
-        models = discretize_homogeneous([L0, LX, LY], dt, order)
+        tot = total or B
+        xi = rng.standard_normal(tot)[offset:offset + B]
+        zeta = rng.standard_normal(tot)[offset:offset + B]
+        gens = np.stack([alpha0 * liouvillian(P2), liouvillian(HX), liouvillian(HY)])
+        scales = np.stack([1 + 0.05 * xi, 1 + 0.02 * zeta, 1 + 0.02 * zeta], axis=1)
+        models = None
+        if host_models:
+            models = discretize_homogeneous([scales[:, k, None, None] * gens[k][None] for k in range(3)], dt, order)
         plant0, plantk = (alpha0 * P2)[None], np.stack([HX, HY])[None]
     elif config == 4:
         d, m = 4, 3
@@ -108,10 +120,13 @@ def build(config, batch=None, order=1, horizon=None, n_steps=None):
         x0 = np.tile(rho0.reshape(1, -1), (B, 1))
         target = np.kron(_proj(2, 0), _proj(2, 1)).reshape(-1)
         rng = np.random.default_rng(4)
-        J = 1 + 0.1 * rng.standard_normal(B)
-        L0 = J[:, None, None] * liouvillian(H0)[None]
-        Lk = [np.broadcast_to(liouvillian(h)[None], (B, 16, 16)) for h in Hk]
-        models = discretize_homogeneous([L0] + Lk, dt, order)
+        tot = total or B
+        J = 1 + 0.1 * rng.standard_normal(tot)[offset:offset + B]
+        gens = np.stack([liouvillian(H0)] + [liouvillian(h) for h in Hk])
+        scales = np.concatenate([J[:, None], np.ones((B, 3))], axis=1)
+        models = None
+        if host_models:
+            models = discretize_homogeneous([scales[:, k, None, None] * gens[k][None] for k in range(4)], dt, order)
         plant0, plantk = H0[None], np.stack(Hk)[None]
     else:
         raise ValueError("config must be 1..5")
@@ -119,5 +134,6 @@ def build(config, batch=None, order=1, horizon=None, n_steps=None):
     ns = n_steps or ns
     X_targ, U_targ = _targets(target, ns, T, m)
     return dict(name="config%d" % config, dim_x=d * d, dim_u=m, d=d, order=order, dt=dt, horizon=T, n_steps=ns, sat=sat,
-                du=du, Q=Qm, R=R, Qf=Qm.copy(), x0=np.ascontiguousarray(x0), models=np.ascontiguousarray(models),
+                du=du, Q=Qm, R=R, Qf=Qm.copy(), x0=np.ascontiguousarray(x0),
+                models=None if models is None else np.ascontiguousarray(models), generators=gens, scales=scales,
                 X_targ=X_targ, U_targ=U_targ, plant_op0=plant0, plant_ops=plantk, batch=B)

@@ -50,6 +50,16 @@ struct QpArgs {
   cplx* X_opt; double* U_opt; double* cost; cplx* gains;   // gains: caller buffer or workspace [B][T][n+1][m]
 };
 
+// discretize_homogeneous for B generator sets (vectorize.py:8-49).  gens: S [B|1][1+m][n][n] (row-major), scaled per
+// instance by scales [B][1+m] when given; models: S [B][n][n(1+P)].
+struct DiscArgs {
+  int B;
+  double dt;
+  const void* gens; long gen_stride;
+  const double* scales;
+  void* models;
+};
+
 struct PlantArgs {
   int B, kind;
   double dt;
@@ -67,6 +77,7 @@ struct ShapeOps {
   int (*launch_linearize)(const LinArgs&, hipStream_t);
   int (*launch_qp)(const QpArgs&, hipStream_t);
   int (*launch_plant)(const PlantArgs&, hipStream_t);
+  int (*launch_discretize)(const DiscArgs&, int real_path, hipStream_t);
   int (*power_list)(int32_t* out);
   int (*occupancy)(int plant_kind, int real_path);   // resident workgroups per CU of the fused kernel
 };

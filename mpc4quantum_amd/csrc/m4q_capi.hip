@@ -657,6 +657,76 @@ int m4q_quad_program_batch(int32_t B, int32_t dim_x, int32_t dim_u, int32_t T, i
   return down(gains, d_g, (size_t)B * T * (n + 1) * m * C);
 }
 
+int m4q_discretize_batch(int32_t B, int32_t dim_x, int32_t dim_u, int32_t order, double dt, const double* generators,
+                         int32_t gen_per_instance, const double* scales, double* models) {
+  const m4q::ShapeOps* sh = find_shape(dim_x, dim_u, order);
+  if (!sh) return fail(M4Q_E_UNSUPPORTED, "no kernel for dim_x=%d dim_u=%d order=%d", dim_x, dim_u, order);
+  if (B <= 0 || !generators || !models) return fail(M4Q_E_BADARG, "m4q_discretize_batch: bad argument");
+  int rc = need_device();
+  if (rc) return rc;
+  const size_t n = dim_x, m = dim_u, P = sh->np, C = 16;
+  Tmp t;
+  m4q::DiscArgs a{};
+  a.B = B; a.dt = dt;
+  void *d_g, *d_s = nullptr, *d_m;
+  if ((rc = t.up(generators, (gen_per_instance ? B : 1) * (1 + m) * n * n * C, &d_g))) return rc;
+  if (scales && (rc = t.up(scales, (size_t)B * (1 + m) * 8, &d_s))) return rc;
+  if ((rc = t.up(nullptr, (size_t)B * n * n * (1 + P) * C, &d_m))) return rc;
+  a.gens = d_g; a.gen_stride = gen_per_instance ? (long)((1 + m) * n * n) : 0;
+  a.scales = (const double*)d_s; a.models = d_m;
+  rc = sh->launch_discretize(a, 0, nullptr);
+  if (rc) return fail(rc, "discretize launch failed");
+  HIP_TRY(hipDeviceSynchronize());
+  return down(models, d_m, (size_t)B * n * n * (1 + P) * C);
+}
+
+int m4q_session_build_models(m4q_session* s, double dt, const double* generators, int32_t gen_per_instance,
+                             const double* scales) {
+  if (!s || !generators) return fail(M4Q_E_BADARG, "m4q_session_build_models: bad argument");
+  const m4q_problem& p = s->prob;
+  const size_t n = p.dim_x, m = p.dim_u, P = s->shape->np, C = 16;
+  const size_t nset = gen_per_instance ? (size_t)s->B : 1;
+  const size_t nmodels = p.model_per_instance ? (size_t)s->B : 1;
+  if ((gen_per_instance || scales) && !p.model_per_instance)
+    return fail(M4Q_E_BADARG, "per-instance generators or scales need model_per_instance = 1");
+  Tmp t;
+  m4q::DiscArgs a{};
+  a.B = (int)nmodels; a.dt = dt;
+  void *d_g, *d_s = nullptr;
+  int rc;
+  if ((rc = t.up(generators, nset * (1 + m) * n * n * C, &d_g))) return rc;
+  if (scales && (rc = t.up(scales, (size_t)s->B * (1 + m) * 8, &d_s))) return rc;
+  a.gens = d_g; a.gen_stride = gen_per_instance ? (long)((1 + m) * n * n) : 0;
+  a.scales = (const double*)d_s; a.models = s->f[M4Q_F_MODELS].p;
+  rc = s->shape->launch_discretize(a, 0, s->stream);
+  if (rc) return fail(rc, "discretize launch failed");
+  s->herm_ok[M4Q_F_MODELS] = false;
+  if (!s->force_complex) {
+    // the same expansion in the Hermitian operator basis: lift the generators (few, or one set per member)
+    const HermBasis hb(s->shape->d);
+    const auto* g = reinterpret_cast<const std::complex<double>*>(generators);
+    std::vector<std::complex<double>> tmp(n * n);
+    std::vector<double> lifted(nset * (1 + m) * n * n);
+    LiftStat st;
+    for (size_t q = 0; q < nset * (1 + m); ++q) {
+      hb.lift_mat(g + q * n * n, (long)n, tmp.data(), (long)n);
+      for (size_t e = 0; e < n * n; ++e) { st.see(tmp[e]); lifted[q * n * n + e] = tmp[e].real(); }
+    }
+    if (st.real_enough()) {
+      void* d_gr;
+      if ((rc = t.up(lifted.data(), lifted.size() * 8, &d_gr))) return rc;
+      if ((rc = s->r_models.alloc(nmodels * n * n * (1 + P) * 8))) return rc;
+      m4q::DiscArgs r = a;
+      r.gens = d_gr; r.models = s->r_models.p;
+      rc = s->shape->launch_discretize(r, 1, s->stream);
+      if (rc) return fail(rc, "discretize launch failed");
+      s->herm_ok[M4Q_F_MODELS] = true;
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return 0;
+}
+
 int m4q_plant_step_batch(int32_t B, int32_t dim_x, int32_t dim_u, int32_t plant_kind, double dt, const double* x,
                          const double* u, const double* op0, const double* ops, int32_t plant_per_instance,
                          double* x_next) {

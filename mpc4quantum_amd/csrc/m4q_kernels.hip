@@ -522,6 +522,89 @@ __global__ __launch_bounds__(64) M4Q_OCC void plant_kernel(PlantArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// discretize_homogeneous for B generator sets (vectorize.py:8-49): Taylor/Dyson expansion of
+// exp(dt (G_0 + sum_k u_k G_k)) to ORDER, every word of operators multiplied out and binned by its control
+// monomial.  One row per instance; generators staged in LDS, products column-owned in registers.
+// ---------------------------------------------------------------------------------------------
+constexpr int find_monomial(int c0, int c1, int c2) {
+  constexpr PowTab<NU, ORDER> tab{};
+  const int want[3] = {c0, c1, c2};
+  for (int p = 0; p < PowTab<NU, ORDER>::COUNT; ++p) {
+    bool same = true;
+    for (int k = 0; k < NU; ++k) same = same && tab.e[p][k] == want[k];
+    if (same) return p;
+  }
+  return -1;
+}
+constexpr int word_block(int a, int b) {      // monomial of a word of one (b < 0) or two letters; letter 0 = drift
+  int c[3] = {0, 0, 0};
+  if (a > 0) ++c[a - 1];
+  if (b > 0) ++c[b - 1];
+  return find_monomial(c[0], c[1], c[2]);
+}
+
+template <class S>
+__global__ __launch_bounds__(64) void discretize_kernel(DiscArgs a) {
+  static_assert(ORDER == 1 || ORDER == 2, "orders 1 and 2 are compiled");
+  S* lds = reinterpret_cast<S*>(m4q_lds_raw);
+  const LaneGeo L;
+  const int g = L.g, jj = L.jj, j = L.j;
+  constexpr int GEN_ELEMS = (1 + NU) * NX * NX;
+  constexpr int W = NX * (1 + NP);
+  S* G = lds + g * GEN_ELEMS;                      // [1+m][n][n] row-major, scaled
+  const int nquads = (a.B + ROWS - 1) / ROWS;
+  const S* gens = static_cast<const S*>(a.gens);
+  S* models = static_cast<S*>(a.models);
+  for (int quad = blockIdx.x; quad < nquads; quad += gridDim.x) {
+    const long q0 = (long)quad * ROWS;
+    const bool valid = q0 + g < a.B;
+    const long b = valid ? q0 + g : a.B - 1;
+    wave_sync();
+    for (int e = jj; e < GEN_ELEMS; e += 16) {
+      const double sc = a.scales ? a.scales[b * (1 + NU) + e / (NX * NX)] : 1.0;
+      G[e] = cscale(gens[b * a.gen_stride + e], sc);
+    }
+    wave_sync();
+    S* out = models + b * (long)NX * W;
+    // accumulate every block's column j in registers: blk[p][i]
+    S blk[1 + NP][NX];
+#pragma unroll
+    for (int p = 0; p <= NP; ++p)
+#pragma unroll
+      for (int i = 0; i < NX; ++i) blk[p][i] = zero_of<S>();
+#pragma unroll
+    for (int i = 0; i < NX; ++i) blk[0][i] = from_real<S>(i == j ? 1.0 : 0.0);       // k = 0: identity
+    static_for<0, 1 + NU>([&](auto aa) {
+      constexpr int la = decltype(aa)::value;
+      S Ga[NX];                                       // column j of G_a
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Ga[i] = G[(la * NX + i) * NX + j];
+      constexpr int p1 = word_block(la, -1);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) cmac_r(blk[p1][i], Ga[i], a.dt);                    // k = 1: dt G_a
+      if constexpr (ORDER >= 2) {
+        static_for<0, 1 + NU>([&](auto bb) {
+          constexpr int lb = decltype(bb)::value;
+          S Gb[NX], prod[NX];
+#pragma unroll
+          for (int i = 0; i < NX; ++i) Gb[i] = G[(lb * NX + i) * NX + j];
+          matmul_cols<NX>(prod, Ga, Gb);             // column j of G_a G_b (word "a then b": entry @ A_a @ A_b)
+          constexpr int p2 = word_block(la, lb);
+#pragma unroll
+          for (int i = 0; i < NX; ++i) cmac_r(blk[p2][i], prod[i], 0.5 * a.dt * a.dt);
+        });
+      }
+    });
+    if (valid && L.lane_ok) {
+#pragma unroll
+      for (int p = 0; p <= NP; ++p)
+#pragma unroll
+        for (int i = 0; i < NX; ++i) out[i * W + p * NX + j] = blk[p][i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host-side launchers for this shape
 // ---------------------------------------------------------------------------------------------
 static size_t mpc_lds_bytes(int real_path) { return real_path ? mpc_lds_layout_bytes<double>() : mpc_lds_layout_bytes<cplx>(); }
@@ -600,6 +683,13 @@ static int launch_plant(const PlantArgs& a, hipStream_t s) {
   return -(int)hipGetLastError();
 }
 
+static int launch_discretize(const DiscArgs& a, int real_path, hipStream_t s) {
+  const size_t elems = (size_t)ROWS * (1 + NU) * NX * NX;
+  if (real_path) hipLaunchKernelGGL(discretize_kernel<double>, dim3(grid_for(a.B)), dim3(64), elems * sizeof(double), s, a);
+  else hipLaunchKernelGGL(discretize_kernel<cplx>, dim3(grid_for(a.B)), dim3(64), elems * sizeof(cplx), s, a);
+  return -(int)hipGetLastError();
+}
+
 static int power_list(int32_t* out) {
   constexpr PowTab<NU, ORDER> tab{};
   for (int p = 0; p < PowTab<NU, ORDER>::COUNT; ++p)
@@ -609,7 +699,7 @@ static int power_list(int32_t* out) {
 
 static const ShapeOps* shape_ops() {
   static const ShapeOps ops = {NX, NU, ORDER, NP, DD, mpc_lds_bytes, launch_mpc, launch_linearize, launch_qp, launch_plant,
-                               power_list, occupancy};
+                               launch_discretize, power_list, occupancy};
   return &ops;
 }
 

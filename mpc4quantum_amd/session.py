@@ -74,6 +74,14 @@ class EnsembleSession:
     def bind_output(self, field, device_ptr, nbytes):
         _lib.check(self._L.m4q_session_bind_output(self._h, field, C.c_void_p(device_ptr), nbytes))
 
+    def build_models(self, dt, generators, scales=None):
+        """Fill the MODELS field on the device: generators [1+m, n, n] (shared) or [B, 1+m, n, n], scales [B, 1+m]."""
+        g = np.ascontiguousarray(generators, dtype=np.complex128)
+        per = 1 if g.ndim == 4 and g.shape[0] > 1 else 0
+        sc = None if scales is None else np.ascontiguousarray(scales, dtype=np.float64)
+        _lib.check(self._L.m4q_session_build_models(self._h, float(dt), g.ctypes.data_as(_lib._dp), per,
+                                                    sc.ctypes.data_as(_lib._dp) if sc is not None else None))
+
     def run(self, step_begin=0, step_end=None):
         _lib.check(self._L.m4q_session_run(self._h, int(step_begin), int(self.problem.n_steps if step_end is None else step_end)))
 
@@ -107,7 +115,8 @@ class EnsembleSession:
         axis), models [B|1, n, n(1+P)] (or [n, n(1+P)])."""
         p = self.problem
         n, m, cols = p.dim_x, p.dim_u, p.target_cols
-        self.upload(_lib.F_MODELS, models)
+        if models is not None:                       # None: already built on the device (build_models)
+            self.upload(_lib.F_MODELS, models)
         self.upload(_lib.F_X0, x0)
         Xt = np.asarray(X_targ, dtype=np.complex128)
         Ut = np.real(np.asarray(U_targ)).astype(np.float64)

@@ -39,6 +39,35 @@ def discretize_homogeneous(A_cts_list, dt, order):
     return res if batched else res[0]
 
 
+def discretize_homogeneous_batch(A_cts_list, dt, order, scales=None):
+    """GPU form of discretize_homogeneous for an ensemble (HIP kernel `discretize_kernel` through
+    m4q_discretize_batch).  Operators [n, n] (shared) or [B, n, n] (per member); ``scales`` [B, 1+m] multiplies
+    operator k of member b (parameter ensembles over a few fixed operators).  Returns [B, n, n(1+P)]."""
+    from . import _lib
+    ops = [np.asarray(a, dtype=np.complex128) for a in A_cts_list]
+    per = any(a.ndim == 3 for a in ops)
+    n = ops[0].shape[-1]
+    m = len(ops) - 1
+    if per:
+        Bn = max(a.shape[0] for a in ops if a.ndim == 3)
+        gens = np.stack([np.broadcast_to(a, (Bn, n, n)) for a in ops], axis=1)
+    else:
+        gens = np.stack(ops)[None]
+    if scales is not None:
+        scales = np.ascontiguousarray(scales, dtype=np.float64)
+        Bn = scales.shape[0]
+    elif not per:
+        Bn = 1
+    L = _lib.lib()
+    P = L.m4q_library_size(order, m)
+    out = np.empty((Bn, n, n * (1 + P)), dtype=np.complex128)
+    gens = np.ascontiguousarray(gens)
+    _lib.check(L.m4q_discretize_batch(Bn, n, m, order, float(dt), gens.ctypes.data_as(_lib._dp), 1 if per else 0,
+                                      scales.ctypes.data_as(_lib._dp) if scales is not None else None,
+                                      out.ctypes.data_as(_lib._dp)))
+    return out
+
+
 def liouvillian(H):
     """Generator of d/dt vec_r(rho) = -i [H, rho] in the |i><j| basis, i-major:
     -i (H (x) I - I (x) H^T).  Equals vectorize_me(H, [|i><j|]) (vectorize.py:52-75)."""

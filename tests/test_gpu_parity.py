@@ -73,6 +73,56 @@ def test_unsupported_shape_raises():
         m4q.WrapModel(np.eye(4), np.zeros((4, 12)), 1, 1)
 
 
+# ---------------------------------------------------------------- model construction
+@pytest.mark.parametrize("d,m,order", [(2, 1, 1), (2, 1, 2), (3, 2, 1), (3, 2, 2), (4, 3, 1)])
+def test_discretize_batch_vs_oracle(d, m, order):
+    """vectorize.discretize_homogeneous on the device: shared operators, per-member operators, per-member scales."""
+    rng = np.random.default_rng(40 + d)
+    n = d * d
+    Bn = 7
+    Hs = [(lambda M: M + M.conj().T)(rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))) for _ in range(m + 1)]
+    Ls = [m4q.liouvillian(H) + 0.1 * (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))) for H in Hs]
+    dt = 0.3
+    shared = m4q.discretize_homogeneous_batch(Ls, dt, order)
+    assert shared.shape[0] == 1 and rel(shared[0], orc.discretize_homogeneous(Ls, dt, order)) <= 1e-13
+    per = [np.stack([L * (1 + 0.1 * b) for b in range(Bn)]) for L in Ls]
+    out = m4q.discretize_homogeneous_batch(per, dt, order)
+    scales = 1 + 0.1 * rng.standard_normal((Bn, m + 1))
+    out_s = m4q.discretize_homogeneous_batch(Ls, dt, order, scales=scales)
+    for b in range(Bn):
+        assert rel(out[b], orc.discretize_homogeneous([L[b] for L in per], dt, order)) <= 1e-13
+        assert rel(out_s[b], orc.discretize_homogeneous([scales[b, k] * Ls[k] for k in range(m + 1)], dt, order)) <= 1e-13
+
+
+def test_discretize_known_answer_on_device():
+    """reference tests/test_mpc4quantum.py:147-188 shape of statement: order 1 gives [I + dt A | dt N_k]."""
+    rng = np.random.default_rng(1)
+    Ls = [rng.standard_normal((9, 9)) + 1j * rng.standard_normal((9, 9)) for _ in range(3)]
+    out = m4q.discretize_homogeneous_batch(Ls, 1.0, 1)[0]
+    assert np.allclose(out, np.hstack([Ls[0] + np.identity(9), Ls[1], Ls[2]]), rtol=0, atol=1e-14)
+
+
+def test_session_build_models_matches_uploaded_models():
+    """Models built on the device from generators and scales (no model crosses PCIe) give the same closed loop as
+    host-built, uploaded models, on the real path (both take it) and on the complex path."""
+    p = configs.build(3, batch=6, horizon=12, n_steps=6)
+    ref = _gpu_batch(p, np.arange(6))
+    for fc in (False, True):
+        sess = _session(p, 6, force_complex=fc)
+        try:
+            sess.build_models(p["dt"], p["generators"], p["scales"])
+            sess.load_problem(None, p["x0"], p["X_targ"], p["U_targ"], p["Q"], p["R"], p["Qf"], p["plant_op0"], p["plant_ops"])
+            assert sess.path() == ("complex" if fc else "real")
+            got = sess.download(_lib.F_MODELS, (6, 9, 27))
+            assert rel(got, p["models"]) <= 1e-14
+            sess.run()
+            r = sess.results()
+        finally:
+            sess.close()
+        assert np.array_equal(r["qp_solves"], ref["qp_solves"])
+        assert rel(np.swapaxes(r["us"], 1, 2), ref["us"]) <= 1e-7 and rel(r["us"][:, 0], ref["us"][:, :, 0]) <= 1e-11
+
+
 # ---------------------------------------------------------------- QP / Riccati
 @pytest.mark.parametrize("name,order", SYSTEMS)
 @pytest.mark.parametrize("tag", ["free", "sat"])
