@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--config", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="ensemble members per GPU (default: the config's own size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="collective backend for N > 1: nccl (= RCCL over xGMI, the real thing) or "
+                                                      "gloo (rehearsal on a box with fewer GPUs than ranks: results staged through the host)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -79,9 +81,14 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        ndev = torch.cuda.device_count()
+        dev_index = local_rank if args.backend == "nccl" else local_rank % max(ndev, 1)
+        torch.cuda.set_device(dev_index)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend="gloo")
 
     import numpy as np
     from mpc4quantum_amd import _lib, configs
@@ -96,7 +103,7 @@ def main():
     per_model = p["scales"] is not None
 
     sess = EnsembleSession(B, n, m, p["order"], T, ns, p["dt"], p["sat"], p["du"], model_per_instance=per_model,
-                           target_cols=ns + T + 1, device=local_rank if world > 1 else -1)
+                           target_cols=ns + T + 1, device=dev_index if world > 1 else -1)
     gather_bufs = None
     if world > 1:
         # results live in torch-owned HBM so RCCL can gather them without a copy
@@ -120,6 +127,13 @@ def main():
             sess.sync()
             us_t, us_all = gather_bufs
             xs_final = xs_t.view(B, ns + 1, n * 2)[:, -1, :].contiguous()
+            if args.backend != "nccl":                             # rehearsal: gloo moves host tensors
+                xs_final, us_src = xs_final.cpu(), us_t.cpu()
+                outs = [torch.empty_like(xs_final) for _ in range(world)] if rank == 0 else None
+                dist.gather(xs_final, outs, dst=0)
+                chunks = [torch.empty_like(us_src) for _ in range(world)] if rank == 0 else None
+                dist.gather(us_src, chunks, dst=0)
+                return
             outs = [torch.empty_like(xs_final) for _ in range(world)] if rank == 0 else None
             dist.gather(xs_final, outs, dst=0)                     # the one RCCL collective of the job
             chunks = list(us_all.chunk(world)) if rank == 0 else None
@@ -148,7 +162,8 @@ def main():
     ok = int((res["exit_codes"] == 0).sum())
     info = sess.info()
     if world > 1:
-        t = torch.tensor([elapsed, float(units_per_step), float(ok)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, float(units_per_step), float(ok)], dtype=torch.float64,
+                         device="cuda" if args.backend == "nccl" else "cpu")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
