@@ -183,7 +183,7 @@ def main():
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get("config%d_B%d" % (args.config, B))
+                traffic = json.load(open(tf)).get("config%d_B%d_%s" % (args.config, B, path))
             except Exception:
                 traffic = None
         out = {
@@ -201,7 +201,9 @@ def main():
                          "frac": flops / avg_launch_s / 1e12 / PEAK_F64_TFLOPS, "traffic": traffic,
                          "kernel": "mpc_kernel<%s, PLANT_HAMILTONIAN>" % ("double" if path == "real" else "cplx"), "launches": launches, "avg_launch_ms": 1e3 * avg_launch_s,
                          "note": "fp64 compute roof: v_fma_f64 (VALU, used here with DPP row broadcasts) and v_mfma_f64 share the "
-                                 "78.6 TFLOP/s dense rate on MI355X; algorithmic flops = 27 kflop/horizon-step (SURVEY 8d)",
+                                 "78.6 TFLOP/s dense rate on MI355X; achieved = ALGORITHMIC flops (SURVEY 8d, complex recursion) / launch time. "
+                                 "The real path executes a quarter of them: its executed-FMA issue rate is 47% of peak, the complex path's 72% "
+                                 "(PMC, DESIGN.md section 5)",
                          "hbm": {"achieved": abytes / avg_launch_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": abytes / avg_launch_s / 1e9 / PEAK_HBM_GBS}},
         }
