@@ -467,6 +467,17 @@ class OracleQExperiment:
         return np.stack(xs, axis=1)
 
 
+class OracleLExperiment(OracleQExperiment):
+    """Same duck type for a general generator on vec_r(rho): x' = (L0 + sum_k u_k L_k) x."""
+
+    def simulate(self, x0, ts, u_fn):
+        xs = [np.reshape(x0, -1)]
+        for a, b in zip(ts[:-1], ts[1:]):
+            u = np.reshape(u_fn(a), -1) if callable(u_fn) else np.reshape(u_fn, -1)
+            xs.append(plant_step_generator(xs[-1], u, self.H0, self.H1_list, b - a))
+        return np.stack(xs, axis=1)
+
+
 def mpc(x0, dim_u, order, X_targ, U_targ, clock, experiment, model, Q, R, Qf, sat=None, du=None, max_iter=100,
         exit_condition=None, warm_start=True, qp_mode="qp", count=None, trace=None):
     """Receding-horizon loop restating mpc.py:128-304 for measure_freq == 1, streaming == False,
@@ -543,7 +554,7 @@ def mpc(x0, dim_u, order, X_targ, U_targ, clock, experiment, model, Q, R, Qf, sa
 
 
 def mpc_batch(x0s, A_models, dim_u, order, X_targ, U_targ, dt, horizon, n_steps, H0s, H_list, Q, R, Qf,
-              sat, du, max_iter=100, warm_start=True, qp_mode="qp", trace=None):
+              sat, du, max_iter=100, warm_start=True, qp_mode="qp", trace=None, generator_plant=False):
     """Loop ``mpc`` over an ensemble.  x0s (B, n); A_models (B or 1, n, n(1+P)); H0s (B or 1, d, d).
     Returns xs (B, n, n_steps+1) (NaN-padded after an early exit), us (B, m, n_steps),
     exit codes (B,), QP solves per MPC step (B, n_steps)."""
@@ -558,11 +569,15 @@ def mpc_batch(x0s, A_models, dim_u, order, X_targ, U_targ, dt, horizon, n_steps,
     for b in range(B):
         Am = A_models[b if A_models.shape[0] > 1 else 0]
         model = OracleDMDc(n, n, Am.shape[1] - n, Am)
-        exp = OracleQExperiment(H0s[b if H0s.shape[0] > 1 else 0], H_list)
+        Hl = np.asarray(H_list)
+        Hl = Hl[b] if Hl.ndim == 4 else Hl                       # per-member plant operators [B, m, k, k]
+        X_t = X_targ[b] if np.ndim(X_targ) == 3 else X_targ      # per-member targets [B, n, cols]
+        U_t = U_targ[b] if np.ndim(U_targ) == 3 else U_targ
+        exp = (OracleLExperiment if generator_plant else OracleQExperiment)(H0s[b if H0s.shape[0] > 1 else 0], list(Hl))
         clock = OracleClock(dt, horizon, n_steps)
         cnt = []
         tr = [] if trace is not None else None
-        (xs, us), _, code = mpc(x0s[b], dim_u, order, X_targ, U_targ, clock, exp, model, Q, R, Qf, sat=sat, du=du,
+        (xs, us), _, code = mpc(x0s[b], dim_u, order, X_t, U_t, clock, exp, model, Q, R, Qf, sat=sat, du=du,
                                 max_iter=max_iter, warm_start=warm_start, qp_mode=qp_mode, count=cnt, trace=tr)
         if trace is not None:
             trace.append(tr)

@@ -554,6 +554,62 @@ def test_real_and_complex_paths_agree_and_fallback_rules():
     assert _gpu_batch(q, idx)["path"] == "complex"
 
 
+@pytest.mark.parametrize("path", ["real", "complex"])
+def test_closed_loop_per_member_targets_and_plants(path):
+    """target_per_instance and plant_per_instance: every member tracks its own (ramped) target through its own plant."""
+    p = configs.build(3, batch=5, horizon=10, n_steps=6)
+    rng = np.random.default_rng(21)
+    cols = p["X_targ"].shape[1]
+    ramp = np.minimum(1.0, (np.arange(cols) + 1) / 4.0)
+    Xt = np.stack([p["X_targ"] * (ramp * (0.8 + 0.05 * b))[None, :] for b in range(5)])
+    Ut = np.stack([0.01 * b * np.ones((2, cols - 1)) for b in range(5)])
+    H0 = np.stack([p["plant_op0"][0] * (1 + 0.03 * b) for b in range(5)])
+    Hk = np.stack([p["plant_ops"][0] * (1 - 0.02 * b) for b in range(5)])
+    clock = m4q.StepClock(p["dt"], p["horizon"], p["n_steps"])
+    res = m4q.mpc_batch(p["x0"], p["models"], 2, 1, Xt, Ut, clock, H0, Hk, p["Q"], p["R"], p["Qf"], p["sat"], p["du"],
+                        force_complex=(path == "complex"))
+    assert res["path"] == path
+    xs, us, codes, solves = orc.mpc_batch(p["x0"], p["models"], 2, 1, Xt, Ut, p["dt"], p["horizon"], p["n_steps"], H0, Hk,
+                                          p["Q"], p["R"], p["Qf"], p["sat"], p["du"])
+    assert np.array_equal(res["qp_solves"], solves)
+    assert rel(res["us"][:, :, :2], us[:, :, :2]) <= 1e-9 and rel(res["xs"][:, :, :3], xs[:, :, :3]) <= 1e-9
+    assert rel(res["us"], us) <= 1e-6 and rel(res["xs"], xs) <= 1e-6
+
+
+def test_closed_loop_generator_plant_with_dissipation():
+    """M4Q_PLANT_GENERATOR in the loop: Liouvillian plus amplitude damping (the plant is not unitary)."""
+    p = configs.build(1, batch=1)
+    a = np.array([[0, 1], [0, 0]], dtype=complex)
+    def lind(c):
+        cd = c.conj().T
+        return np.kron(c, c.conj()) - 0.5 * (np.kron(cd @ c, np.eye(2)) + np.kron(np.eye(2), (cd @ c).T))
+    L0 = m4q.liouvillian(p["plant_op0"][0]) + 0.02 * lind(a)
+    Lk = np.stack([m4q.liouvillian(h) for h in p["plant_ops"][0]])
+    clock = m4q.StepClock(p["dt"], p["horizon"], p["n_steps"])
+    res = m4q.mpc_batch(p["x0"], p["models"], 1, 1, p["X_targ"], p["U_targ"], clock, L0, Lk, p["Q"], p["R"], p["Qf"], p["sat"],
+                        p["du"], plant_kind=_lib.PLANT_GENERATOR)
+    xs, us, codes, solves = orc.mpc_batch(p["x0"], p["models"], 1, 1, p["X_targ"], p["U_targ"], p["dt"], p["horizon"],
+                                          p["n_steps"], L0[None], list(Lk), p["Q"], p["R"], p["Qf"], p["sat"], p["du"],
+                                          generator_plant=True)
+    assert np.array_equal(res["qp_solves"], solves)
+    assert rel(res["us"][:, :, :3], us[:, :, :3]) <= 1e-9 and rel(res["xs"][:, :, :4], xs[:, :, :4]) <= 1e-9
+    assert rel(res["us"], us) <= 1e-4 and rel(res["xs"], xs) <= 1e-4         # free running: conditioning of the loop (DESIGN.md 3)
+    assert abs(res["xs"][0, 0, -1] + res["xs"][0, 3, -1] - 1) < 1e-10        # trace preserved by the Lindbladian
+
+
+def test_closed_loop_long_horizon_config5_shape():
+    """BASELINE config 5's shape (T = 80) on two members, and the degenerate n_steps = 1 / T = 2 corner."""
+    p = configs.build(5, batch=2, n_steps=4)
+    res = _gpu_batch(p, np.arange(2))
+    xs, us, codes, solves = _oracle_batch(p, np.arange(2))
+    assert np.array_equal(res["qp_solves"], solves)
+    assert rel(res["us"][:, :, 0], us[:, :, 0]) <= 1e-10 and rel(res["us"], us) <= 1e-6
+    q = configs.build(2, batch=3, horizon=2, n_steps=1)
+    res = _gpu_batch(q, np.arange(3))
+    xs, us, codes, solves = _oracle_batch(q, np.arange(3))
+    assert np.array_equal(res["qp_solves"], solves) and rel(res["us"], us) <= 1e-10 and rel(res["xs"], xs) <= 1e-10
+
+
 def test_exit_code_3_on_nonfinite_model():
     p = configs.build(2, batch=5)
     models = np.repeat(p["models"], 5, axis=0)
