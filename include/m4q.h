@@ -62,7 +62,7 @@ extern "C" {
  * 2 reserved (solver warning: cannot occur without OSQP), 3 non-finite objective */
 
 typedef struct m4q_problem {
-  int32_t dim_x;   /* n = d*d: 4, 9 or 16 */
+  int32_t dim_x;   /* n = d*d: 4, 9 or 16; also 8 (two reduced qubit states, experiment.py:238-306) with M4Q_PLANT_NONE */
   int32_t dim_u;   /* m */
   int32_t order;   /* control-library order (1 or 2) */
   int32_t horizon; /* T (StepClock.horizon, mpc.py:17) */

@@ -2,7 +2,8 @@
 
 Same public names as the reference package (mpc4quantum/__init__.py:3-7 star-exports experiment,
 linearize, model, mpc, vectorize), backed by hand-written HIP kernels in libm4q_hip.so."""
-from .experiment import Experiment, LExperiment, QExperiment, plant_step_batch  # noqa: F401
+from .experiment import (Experiment, LExperiment, QCoupledExperiment, QExperiment, QExperiment32, isqrt,  # noqa: F401
+                         plant_step_batch)
 from .library import (create_library, create_library_from_list, create_power_list, diff_library, krtimes,  # noqa: F401
                       multinomial_powers, size_of_library)
 from .linearize import WrapModel  # noqa: F401

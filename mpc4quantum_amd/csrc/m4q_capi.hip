@@ -239,7 +239,11 @@ int m4q_session_create(const m4q_problem* p, int32_t B, int32_t device, m4q_sess
   s->prob = *p;
   s->B = B;
   s->shape = sh;
-  s->force_complex = (p->reserved & 1) != 0 || std::getenv("M4Q_FORCE_COMPLEX") != nullptr;
+  s->force_complex = (p->reserved & 1) != 0 || std::getenv("M4Q_FORCE_COMPLEX") != nullptr || sh->d * sh->d != p->dim_x;
+  if (sh->d * sh->d != p->dim_x && p->plant_kind != M4Q_PLANT_NONE) {
+    delete s;
+    return fail(M4Q_E_UNSUPPORTED, "dim_x=%d is not a vectorised density matrix: no device plant (use M4Q_PLANT_NONE)", p->dim_x);
+  }
   HIP_TRY(hipGetDevice(&s->device));
   HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&s->ev0));

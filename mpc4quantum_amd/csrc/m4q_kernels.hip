@@ -20,12 +20,14 @@ namespace M4Q_CAT(shape_, M4Q_NX, M4Q_NU, M4Q_ORDER) {
 constexpr int NX = M4Q_NX;
 constexpr int NU = M4Q_NU;
 constexpr int ORDER = M4Q_ORDER;
-constexpr int DD = (NX == 4) ? 2 : (NX == 9) ? 3 : 4;
-static_assert(DD * DD == NX, "dim_x must be 4, 9 or 16");
+// n = d*d for vectorised density matrices.  A model space that is not a square (n = 8: two reduced qubit states,
+// experiment.py:238-306) has no device plant and no Hermitian-basis path: only the complex QP machinery is built.
+constexpr int DD = (NX == 4) ? 2 : (NX == 9) ? 3 : (NX == 16) ? 4 : 1;
+constexpr bool SQUARE = DD * DD == NX;
 constexpr int NP = PowTab<NU, ORDER>::NP;
 constexpr int PITCH = ModelPitch<NX>::value;
 constexpr int MODEL_ELEMS = (1 + NP) * NX * PITCH;        // per instance, elements (of S) in LDS
-constexpr int SCRATCH_ELEMS = DD * DD + 2 * NX;           // plant / basis-change scratch per instance (complex)
+constexpr int SCRATCH_ELEMS = (SQUARE ? DD * DD : 0) + 2 * NX;   // plant / basis-change scratch per instance (complex)
 constexpr int ROWS = 4;                                    // instances per wavefront
 
 // register budget: waves per SIMD the kernels are compiled for (512 / budget VGPRs per lane)
@@ -628,6 +630,10 @@ static int launch_mpc_t(const MpcArgs& a, int grid, hipStream_t s) {
 }
 
 static int launch_mpc(const MpcArgs& a, int plant_kind, int real_path, int grid, hipStream_t s) {
+  if constexpr (!SQUARE) {
+    if (real_path || plant_kind != PLANT_NONE) return -(int)hipErrorInvalidValue;
+    return launch_mpc_t<cplx, PLANT_NONE>(a, grid, s);
+  } else {
   if (real_path) {
     if (plant_kind == PLANT_HAMILTONIAN) return launch_mpc_t<double, PLANT_HAMILTONIAN>(a, grid, s);
     if (plant_kind == PLANT_GENERATOR) return launch_mpc_t<double, PLANT_GENERATOR>(a, grid, s);
@@ -636,6 +642,7 @@ static int launch_mpc(const MpcArgs& a, int plant_kind, int real_path, int grid,
   if (plant_kind == PLANT_HAMILTONIAN) return launch_mpc_t<cplx, PLANT_HAMILTONIAN>(a, grid, s);
   if (plant_kind == PLANT_GENERATOR) return launch_mpc_t<cplx, PLANT_GENERATOR>(a, grid, s);
   return launch_mpc_t<cplx, PLANT_NONE>(a, grid, s);
+  }
 }
 
 template <class S, int PLANT>
@@ -646,6 +653,9 @@ static int occupancy_t() {
 }
 
 static int occupancy(int plant_kind, int real_path) {
+  if constexpr (!SQUARE) {
+    return (real_path || plant_kind != PLANT_NONE) ? 0 : occupancy_t<cplx, PLANT_NONE>();
+  } else {
   if (real_path) {
     if (plant_kind == PLANT_HAMILTONIAN) return occupancy_t<double, PLANT_HAMILTONIAN>();
     if (plant_kind == PLANT_GENERATOR) return occupancy_t<double, PLANT_GENERATOR>();
@@ -654,6 +664,7 @@ static int occupancy(int plant_kind, int real_path) {
   if (plant_kind == PLANT_HAMILTONIAN) return occupancy_t<cplx, PLANT_HAMILTONIAN>();
   if (plant_kind == PLANT_GENERATOR) return occupancy_t<cplx, PLANT_GENERATOR>();
   return occupancy_t<cplx, PLANT_NONE>();
+  }
 }
 
 static int grid_for(int B) {
@@ -675,15 +686,20 @@ static int launch_qp(const QpArgs& a, hipStream_t s) {
 }
 
 static int launch_plant(const PlantArgs& a, hipStream_t s) {
+  if constexpr (!SQUARE) {
+    return -(int)hipErrorInvalidValue;
+  } else {
   const size_t lds = sizeof(cplx) * (size_t)(ROWS * SCRATCH_ELEMS);
   if (a.kind == PLANT_HAMILTONIAN)
     hipLaunchKernelGGL(plant_kernel<PLANT_HAMILTONIAN>, dim3(grid_for(a.B)), dim3(64), lds, s, a);
   else
     hipLaunchKernelGGL(plant_kernel<PLANT_GENERATOR>, dim3(grid_for(a.B)), dim3(64), lds, s, a);
   return -(int)hipGetLastError();
+  }
 }
 
 static int launch_discretize(const DiscArgs& a, int real_path, hipStream_t s) {
+  if (!SQUARE && real_path) return -(int)hipErrorInvalidValue;
   const size_t elems = (size_t)ROWS * (1 + NU) * NX * NX;
   if (real_path) hipLaunchKernelGGL(discretize_kernel<double>, dim3(grid_for(a.B)), dim3(64), elems * sizeof(double), s, a);
   else hipLaunchKernelGGL(discretize_kernel<cplx>, dim3(grid_for(a.B)), dim3(64), elems * sizeof(cplx), s, a);

@@ -117,3 +117,43 @@ class LExperiment(QExperiment):
         self.ts, self.us = ts, us
         self.xs = np.stack(cols, axis=1)
         return self.xs
+
+
+def isqrt(n):
+    """Integer square root (experiment.py:311-327)."""
+    import math
+    if n < 0:
+        raise ValueError("Square root not defined for negative numbers.")
+    return math.isqrt(int(n))
+
+
+class QExperiment32(QExperiment):
+    """Three-level plant seen through its qubit block (experiment.py:215-235): the model lives on the 2x2 block."""
+
+    @staticmethod
+    def lift(rho33_vec):
+        block = np.reshape(np.asarray(rho33_vec, dtype=np.complex128), (3, 3))[:2, :2]
+        # Qobj.unit(): divide by the trace norm (sum of singular values)
+        return (block / np.linalg.svd(block, compute_uv=False).sum()).flatten()
+
+    @staticmethod
+    def proj(rho22_vec):
+        return np.asarray(rho22_vec).flatten()          # as the reference returns it (experiment.py:231-235)
+
+
+class QCoupledExperiment(QExperiment):
+    """Two identical subsystems: the model sees the two reduced states [vec(rho_A), vec(rho_B)] (partial traces),
+    the plant the joint state (experiment.py:238-306)."""
+
+    @staticmethod
+    def lift(rhoAB_vec):
+        v = np.asarray(rhoAB_vec, dtype=np.complex128).reshape(-1)
+        dA = isqrt(isqrt(v.size))
+        r = v.reshape(dA, dA, dA, dA)                    # r[a, b, a', b'] = <a b| rho |a' b'>
+        return np.hstack([np.einsum('abcb->ac', r).flatten(), np.einsum('abad->bd', r).flatten()])
+
+    @staticmethod
+    def proj(rhoA_rhoB_vec):
+        v = np.asarray(rhoA_rhoB_vec).reshape(-1)
+        dA = isqrt(v.size // 2)
+        return np.kron(v[:dA * dA].reshape(dA, dA), v[dA * dA:].reshape(dA, dA)).flatten()

@@ -478,6 +478,32 @@ class OracleLExperiment(OracleQExperiment):
         return np.stack(xs, axis=1)
 
 
+class OracleQCoupledExperiment(OracleQExperiment):
+    """lift = [partial trace over B, partial trace over A], proj = Kronecker product (experiment.py:247-306)."""
+
+    @staticmethod
+    def lift(rhoAB_vec):
+        v = np.reshape(rhoAB_vec, -1)
+        dAB = int(round(np.sqrt(v.size)))
+        dA = int(round(np.sqrt(dAB)))
+        rho = v.reshape(dAB, dAB)
+        idA = np.identity(dA)
+        rhoA = np.zeros((dA, dA), dtype=complex)
+        rhoB = np.zeros((dA, dA), dtype=complex)
+        for i in range(dA):
+            ket = np.zeros((dA, 1))
+            ket[i] = 1
+            rhoA += np.kron(idA, ket.T) @ rho @ np.kron(idA, ket)
+            rhoB += np.kron(ket.T, idA) @ rho @ np.kron(ket, idA)
+        return np.hstack([rhoA.flatten(), rhoB.flatten()])
+
+    @staticmethod
+    def proj(v):
+        v = np.reshape(v, -1)
+        dA = int(round(np.sqrt(v.size // 2)))
+        return np.kron(v[:dA * dA].reshape(dA, dA), v[dA * dA:].reshape(dA, dA)).flatten()
+
+
 def mpc(x0, dim_u, order, X_targ, U_targ, clock, experiment, model, Q, R, Qf, sat=None, du=None, max_iter=100,
         exit_condition=None, warm_start=True, qp_mode="qp", count=None, trace=None):
     """Receding-horizon loop restating mpc.py:128-304 for measure_freq == 1, streaming == False,

@@ -610,6 +610,42 @@ def test_closed_loop_long_horizon_config5_shape():
     assert np.array_equal(res["qp_solves"], solves) and rel(res["us"], us) <= 1e-10 and rel(res["xs"], xs) <= 1e-10
 
 
+def test_mpc_crosstalk_model_on_reduced_states():
+    """The reference's crosstalk scenario (tests/test_mpc4quantum.py:281-397, tests/util_qubits.py:39-57): the model
+    lives on the two reduced qubit states (n = 8, block diagonal), the plant on the joint 4-level state with a
+    sigma_z sigma_z coupling the model does not know; lift = partial traces, proj = Kronecker product
+    (experiment.py:238-306).  mpc() steps the device QP and evaluates plant and lift through the experiment object."""
+    from mpc4quantum_amd.configs import I2, SX, SY, SZ, rx
+    ct = 0.1
+    H_joint = [0.5 * ct * np.kron(SZ, SZ), 0.5 * np.kron(SX, I2), 0.5 * np.kron(I2, SY)]
+    L1 = [m4q.liouvillian(0 * SX), m4q.liouvillian(SX)]
+    L2 = [m4q.liouvillian(0 * SY), m4q.liouvillian(SY)]
+    z = np.zeros((4, 4))
+    A_cts = [np.block([[L1[0], z], [z, L2[0]]]), np.block([[L1[1], z], [z, z]]), np.block([[z, z], [z, L2[1]]])]
+    dt, T, ns = 0.5, 8, 6
+    A_dst = m4q.discretize_homogeneous(A_cts, dt, 1)
+    sat = 2 * np.pi * 0.1
+    r1, r2 = rx(1e-2), rx(-1e-2)
+    p0 = np.diag([1.0, 0]).astype(complex)
+    p1 = np.diag([0, 1.0]).astype(complex)
+    rho0 = np.kron(r1 @ p0 @ r1.conj().T, r2 @ p0 @ r2.conj().T)
+    target = np.hstack([p1.flatten(), p1.flatten()])
+    X_bm = np.tile(target[:, None], (1, ns + T + 1))
+    U_bm = np.zeros((2, ns + T))
+    Q = np.diag([1.0, 0, 0, 1, 1, 0, 0, 1])
+    R = 1e-2 / sat ** 2 * np.eye(2)
+
+    def run(mod, exp_cls, model_cls, clock_cls, **kw):
+        clock = clock_cls(dt, T, ns)
+        exp = exp_cls(H_joint[0], H_joint[1:])
+        return mod(rho0.flatten(), 2, 1, X_bm, U_bm, clock, exp, model_cls(8, 8, 16, A_dst), Q, R, Q, sat=sat, du=0.5 * sat, **kw)
+    (xs, us), _, code = run(m4q.mpc, m4q.QCoupledExperiment, m4q.DMDc, m4q.StepClock, progress_bar=False)
+    (xo, uo), _, co = run(orc.mpc, orc.OracleQCoupledExperiment, orc.OracleDMDc, orc.OracleClock)
+    assert code == co == 0 and xs.shape == (16, ns + 1) and us.shape == (2, ns)
+    assert rel(us[:, :2], uo[:, :2]) <= 1e-9 and rel(xs[:, :3], xo[:, :3]) <= 1e-9
+    assert rel(us, uo) <= 1e-5 and rel(xs, xo) <= 1e-5
+
+
 def test_exit_code_3_on_nonfinite_model():
     p = configs.build(2, batch=5)
     models = np.repeat(p["models"], 5, axis=0)

@@ -113,6 +113,33 @@ def test_wrapmodel_dimension_check_needs_no_gpu():
     assert wm.lift_u(np.array([[2.0]])).reshape(-1).tolist() == [2.0, 4.0]
 
 
+def test_partial_trace_lift_proj_known_answer():
+    """reference tests/test_mpc4quantum.py:190-213: lift(proj) round-trips product states and not entangled ones."""
+    rng = np.random.default_rng(8)
+
+    def rand_dm(d):
+        M = rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))
+        r = M @ M.conj().T
+        return r / np.trace(r).real
+    for nd in (2, 4):
+        a, b = rand_dm(nd), rand_dm(nd)
+        c = np.kron(a, b)
+        ab = m4q.QCoupledExperiment.lift(c.flatten())
+        assert np.isclose(np.hstack([a.flatten(), b.flatten()]), ab).all()
+        assert np.isclose(ab, orc.OracleQCoupledExperiment.lift(c.flatten())).all()
+        assert np.isclose(m4q.QCoupledExperiment.proj(ab).reshape(nd * nd, nd * nd), c).all()
+        d = rand_dm(nd * nd)
+        back = m4q.QCoupledExperiment.proj(m4q.QCoupledExperiment.lift(d.flatten())).reshape(nd * nd, nd * nd)
+        assert not np.isclose(d, back).all()
+    r3 = rand_dm(3)
+    l2 = m4q.QExperiment32.lift(r3.flatten())
+    assert l2.shape == (4,) and abs(l2[0] + l2[3] - 1) < 1e-14
+    assert np.allclose(l2.reshape(2, 2), r3[:2, :2] / np.trace(r3[:2, :2]))
+    assert m4q.isqrt(16) == 4 and m4q.isqrt(17) == 4 and m4q.isqrt(0) == 0
+    with pytest.raises(ValueError):
+        m4q.isqrt(-1)
+
+
 def test_shard_bounds_cover_everything():
     for B in (1, 7, 64, 65536):
         for world in (1, 2, 3, 8):
@@ -144,7 +171,7 @@ def test_problem_struct_layout_matches_header():
 
 def test_supported_shapes():
     assert _lib.supported(4, 1, 1) and _lib.supported(9, 2, 1) and _lib.supported(9, 2, 2) and _lib.supported(16, 3, 1)
-    assert not _lib.supported(25, 1, 1)
+    assert _lib.supported(8, 2, 1) and not _lib.supported(25, 1, 1)
 
 
 def test_fails_loudly_without_a_gpu():
