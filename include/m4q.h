@@ -76,6 +76,9 @@ typedef struct m4q_problem {
   int32_t target_per_instance;
   int32_t target_cols; /* columns of X_targ; U_targ has the same count (extra ones unused) */
   int32_t reserved;    /* options: bit 0 = M4Q_OPT_FORCE_COMPLEX */
+  int32_t measure_freq; /* StepClock.measure_freq (mpc.py:19,252-267): the plant is measured every measure_freq-th step, the
+                           model closes the loop in between; 0 or 1 = every step */
+  int32_t reserved2;
   double dt;     /* StepClock.dt */
   double sat;    /* |u| <= sat (optimize.py:43, lqr.py:76) */
   double du;     /* first-control band (optimize.py:29-30); ignored without M4Q_QP_DU_BAND */

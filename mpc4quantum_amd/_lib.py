@@ -31,7 +31,8 @@ class Problem(C.Structure):
     """m4q_problem (include/m4q.h)."""
     _fields_ = [(n, C.c_int32) for n in (
         "dim_x", "dim_u", "order", "horizon", "n_steps", "max_iter", "warm_start", "qp_flags", "plant_kind",
-        "model_per_instance", "plant_per_instance", "target_per_instance", "target_cols", "reserved")] + [
+        "model_per_instance", "plant_per_instance", "target_per_instance", "target_cols", "reserved", "measure_freq",
+        "reserved2")] + [
         (n, C.c_double) for n in ("dt", "sat", "du", "ls_tol")]
 
 

@@ -11,7 +11,7 @@ struct cplx;
 // Arrays marked S are complex (cplx) on the general path and double on the real path (models that preserve
 // Hermiticity, expressed in the Hermitian operator basis of m4q_mpc.h); the host picks the kernel.
 struct MpcArgs {
-  int B, T, n_steps, max_iter, warm_start, flags, step_begin, step_end;
+  int B, T, n_steps, max_iter, warm_start, flags, step_begin, step_end, measure_freq;
   double dt, sat, du, ls_tol;
   const void* models;  long model_stride;   // S [B|1][n][n(1+P)]
   const cplx* x0c;                          // [B][n] complex, as given (becomes xs[:, 0])

@@ -470,6 +470,7 @@ int m4q_session_run(m4q_session* s, int32_t step_begin, int32_t step_end) {
   m4q::MpcArgs a{};
   a.B = s->B; a.T = p.horizon; a.n_steps = p.n_steps; a.max_iter = p.max_iter; a.warm_start = p.warm_start;
   a.flags = p.qp_flags; a.step_begin = step_begin; a.step_end = step_end;
+  a.measure_freq = p.measure_freq > 1 ? p.measure_freq : 1;
   a.dt = p.dt; a.sat = p.sat; a.du = p.du; a.ls_tol = p.ls_tol;
   a.models = real_path ? s->r_models.p : s->f[M4Q_F_MODELS].p; a.model_stride = p.model_per_instance ? (long)(n * n * (1 + P)) : 0;
   a.x0c = (const cplx*)s->f[M4Q_F_X0].p;

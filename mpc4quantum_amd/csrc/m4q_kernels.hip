@@ -151,6 +151,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
   int step = 0, iter = 0, code = 0, done_steps = 0;
   int row_begin = a.step_begin, row_end = a.step_end;
   S x_cur = zero_of<S>();
+  S x_meas = zero_of<S>();     // last MEASURED state (xs[k * measure_freq]); equals x_cur when measure_freq == 1
+  const int mf = a.measure_freq;
   double uprev[NU];
 #pragma unroll
   for (int k = 0; k < NU; ++k) uprev[k] = 0.0;
@@ -201,6 +203,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
           // X_guess = tile(x0), U_guess = 0 (mpc.py:141-142); xs[0] = x0 (:160)
           const S x0 = static_cast<const S*>(a.x0s)[b * NX + j];
           x_cur = x0;
+          x_meas = x0;
           if (lane_ok) {
 #pragma unroll 8
             for (int t = 0; t <= T; ++t) Xg.st<S>(t * NX + j, x0);
@@ -221,8 +224,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
         }
         const cplx xc = rs ? a.xs[b * sXs + (long)row_begin * NX + j] : czero();
         const S r = BasisIO<S>::template to_state<NX, DD>(xc, scratch, j, jj);
+        const cplx xm = rs ? a.xs[b * sXs + (long)(row_begin / mf) * mf * NX + j] : czero();
+        const S rm = BasisIO<S>::template to_state<NX, DD>(xm, scratch, j, jj);
         if (rs) {
           x_cur = r;
+          x_meas = rm;
           for (int e = jj; e < T * NU; e += 16) Ug.st<double>(e, a.Ug[b * sU + e]);
           code = a.codes[b];
           done_steps = a.steps_done[b];
@@ -323,12 +329,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
         }
       }
       if constexpr (PLANT != PLANT_NONE && !(M4Q_EXP & 32)) {
-        const cplx xc = BasisIO<S>::template to_complex<NX, DD>(x_cur, scratch, j, jj);
-        cplx xn;
-        if constexpr (PLANT == PLANT_HAMILTONIAN) xn = plant_hamiltonian<NX, NU, DD>(xc, uapp, op0, ops, a.dt, scratch, j, jj);
-        else xn = plant_generator<NX, NU>(xc, uapp, op0, ops, a.dt, j);
-        const S rn = BasisIO<S>::template to_state<NX, DD>(xn, scratch, j, jj);
+        // (step+1) % measure_freq == 0: propagate the plant from the last measured state over the last measure_freq
+        // intervals (mpc.py:252-260); the held controls are stacked newest first against an increasing time grid
+        // (:257), i.e. replayed in reversed order.  Otherwise the model closes the loop (mpc.py:261-267).
+        const bool measure = (step + 1) % mf == 0;
+        cplx xn = czero();
+        if (__any(ok && measure)) {
+          cplx xc = BasisIO<S>::template to_complex<NX, DD>(x_meas, scratch, j, jj);
+          wave_sync();
+          for (int i = 0; i < mf; ++i) {
+            double ui[NU];
+#pragma unroll
+            for (int k = 0; k < NU; ++k)
+              ui[k] = (i == 0 || !(ok && measure)) ? uapp[k] : a.us[b * sUs + (long)(step - i) * NU + k];
+            if constexpr (PLANT == PLANT_HAMILTONIAN) xc = plant_hamiltonian<NX, NU, DD>(xc, ui, op0, ops, a.dt, scratch, j, jj);
+            else xc = plant_generator<NX, NU>(xc, ui, op0, ops, a.dt, j);
+          }
+          xn = xc;
+        }
+        S rn = BasisIO<S>::template to_state<NX, DD>(xn, scratch, j, jj);
+        if (mf > 1 && __any(ok && !measure)) {
+          typename FusedProv<S, NX, NU, ORDER>::Lin lin;
+#pragma unroll
+          for (int k = 0; k < NU; ++k) lin.u[k] = uapp[k];
+          lin.xg = x_cur;
+          S pred, Bdummy[NU], ddummy;
+          prov.rows(lin, x_cur, pred, Bdummy, ddummy);                 // A x + N (polyu (x) x) = A_t(u) x  (model.py:81-93)
+          const cplx pc = BasisIO<S>::template to_complex<NX, DD>(pred, scratch, j, jj);
+          if (!measure) { rn = pred; xn = pc; }
+        }
         if (ok) x_cur = rn;
+        if (ok && measure) x_meas = rn;
         if (ok && lane_ok) a.xs[b * sXs + (long)(step + 1) * NX + j] = xn;
       }
       // shift_guess (mpc.py:71-73,271-272): drop column 0, repeat the last

@@ -102,8 +102,7 @@ def _trim(xs, us, code, done):
 def mpc(x0, dim_u, order, X_targ, U_targ, clock, experiment, model, Q, R, Qf, sat=None, du=None, max_iter=100,
         exit_condition=None, streaming=False, warm_start=True, progress_bar=True, verbose=False):
     """Drop-in for mpc4quantum.mpc.mpc (mpc.py:128-304): returns ([xs, us], model, exit_code)."""
-    if clock.measure_freq != 1:
-        raise NotImplementedError("measure_freq > 1 is not on the accelerated path yet (SURVEY.md 8f rank 4)")
+    mf = int(clock.measure_freq)
     x0 = np.asarray(x0, dtype=np.complex128).reshape(-1)
     lift_x0 = np.asarray(experiment.lift(x0), dtype=np.complex128).reshape(-1)
     A_x, A_u = model.get_discrete()
@@ -116,7 +115,7 @@ def mpc(x0, dim_u, order, X_targ, U_targ, clock, experiment, model, Q, R, Qf, sa
     fused = _native_plant(experiment) and exit_condition is None and not streaming
     kind = experiment.plant_kind if fused else _lib.PLANT_NONE
     sess = EnsembleSession(1, n, dim_u, order, T, ns, clock.dt, sat, du, max_iter, warm_start, plant_kind=kind,
-                           target_cols=cols)
+                           target_cols=cols, measure_freq=mf)
     try:
         op0, ops = experiment.operators() if fused else (None, None)
         sess.load_problem(np.hstack([A_x, A_u])[None], lift_x0[None], X_targ, U_targ, Q, R, Qf, op0, ops)
@@ -147,10 +146,16 @@ def mpc(x0, dim_u, order, X_targ, U_targ, clock, experiment, model, Q, R, Qf, sa
                 break
             u = sess.download(_lib.F_US, (1, ns, dim_u))[0, step]
             us.append(u)
-            ts_step = clock.ts_step(step)
-            held = np.stack([u, u], axis=1)
-            result = experiment.simulate(xs[step], ts_step, _HeldControl(ts_step, held))       # mpc.py:256-260
-            xs.append(np.asarray(result)[:, -1])
+            if (step + 1) % mf == 0:
+                # measure: plant from the last measured state; controls stacked newest first as mpc.py:257 does
+                ts_step = clock.ts_step(step)
+                us_step = np.vstack([us[step - jq] for jq in range(mf)] + [us[step]]).T
+                result = experiment.simulate(xs[step + 1 - mf], ts_step, _HeldControl(ts_step, us_step))   # mpc.py:256-260
+                xs.append(np.asarray(result)[:, -1])
+            else:
+                lx = np.asarray(experiment.lift(xs[step])).reshape(-1, 1)                      # mpc.py:261-267
+                lu = wrapped.lift_u(u.reshape(-1, 1))
+                xs.append(np.asarray(experiment.proj(model.predict(lx, krtimes(lu, lx)))).flatten())
             sess.put_state(step + 1, np.asarray(experiment.lift(xs[step + 1]), dtype=np.complex128).reshape(1, -1))
             if streaming:                                                                      # mpc.py:281-285
                 lu = wrapped.lift_u(u.reshape(-1, 1))
@@ -211,7 +216,7 @@ def mpc_batch(x0, models, dim_u, order, X_targ, U_targ, clock, plant_op0, plant_
     own = session is None
     sess = session or EnsembleSession(Bn, n, dim_u, order, T, ns, clock.dt, sat, du, max_iter, warm_start, qp_flags,
                                       plant_kind, models.shape[0] > 1, per_plant, per_targ, cols, device=device,
-                                      force_complex=force_complex)
+                                      force_complex=force_complex, measure_freq=getattr(clock, "measure_freq", 1))
     try:
         sess.load_problem(models, x0, X_targ, U_targ, Q, R, Qf, op0, ops)
         sess.run(0, ns)

@@ -17,7 +17,7 @@ _DTYPES = {
 class EnsembleSession:
     def __init__(self, B, dim_x, dim_u, order, horizon, n_steps, dt, sat, du=None, max_iter=100, warm_start=True,
                  qp_flags=None, plant_kind=_lib.PLANT_HAMILTONIAN, model_per_instance=False, plant_per_instance=False,
-                 target_per_instance=False, target_cols=None, ls_tol=1e-4, device=-1, force_complex=False):
+                 target_per_instance=False, target_cols=None, ls_tol=1e-4, device=-1, force_complex=False, measure_freq=1):
         if sat is None:
             raise TypeError("sat is required (the reference negates it unconditionally, optimize.py:43 / lqr.py:76)")
         p = _lib.Problem()
@@ -29,6 +29,7 @@ class EnsembleSession:
         p.target_per_instance = int(target_per_instance)
         p.target_cols = int(target_cols if target_cols is not None else n_steps + horizon + 1)
         p.reserved = _lib.OPT_FORCE_COMPLEX if force_complex else 0
+        p.measure_freq = int(measure_freq)
         p.dt, p.sat, p.du, p.ls_tol = float(dt), float(sat), float(du if du is not None else 0.0), float(ls_tol)
         self.problem = p
         self.B = int(B)

@@ -459,11 +459,19 @@ class OracleQExperiment:
     def proj(z):
         return z
 
+    @staticmethod
+    def _held(u_fn, i, t):
+        """Control held on interval i starting at time t: a callable of time, an (m, len(ts)) array whose column i
+        is held on [ts[i], ts[i+1]) (interp1d kind='previous', mpc.py:258), or one control vector."""
+        if callable(u_fn):
+            return np.reshape(u_fn(t), -1)
+        u = np.asarray(u_fn)
+        return u[:, i] if u.ndim == 2 else np.reshape(u, -1)
+
     def simulate(self, x0, ts, u_fn):
         xs = [np.reshape(x0, -1)]
-        for a, b in zip(ts[:-1], ts[1:]):
-            u = np.reshape(u_fn(a), -1) if callable(u_fn) else np.reshape(u_fn, -1)
-            xs.append(plant_step(xs[-1], u, self.H0, self.H1_list, b - a))
+        for i, (a, b) in enumerate(zip(ts[:-1], ts[1:])):
+            xs.append(plant_step(xs[-1], self._held(u_fn, i, a), self.H0, self.H1_list, b - a))
         return np.stack(xs, axis=1)
 
 
@@ -472,9 +480,8 @@ class OracleLExperiment(OracleQExperiment):
 
     def simulate(self, x0, ts, u_fn):
         xs = [np.reshape(x0, -1)]
-        for a, b in zip(ts[:-1], ts[1:]):
-            u = np.reshape(u_fn(a), -1) if callable(u_fn) else np.reshape(u_fn, -1)
-            xs.append(plant_step_generator(xs[-1], u, self.H0, self.H1_list, b - a))
+        for i, (a, b) in enumerate(zip(ts[:-1], ts[1:])):
+            xs.append(plant_step_generator(xs[-1], self._held(u_fn, i, a), self.H0, self.H1_list, b - a))
         return np.stack(xs, axis=1)
 
 
@@ -506,7 +513,7 @@ class OracleQCoupledExperiment(OracleQExperiment):
 
 def mpc(x0, dim_u, order, X_targ, U_targ, clock, experiment, model, Q, R, Qf, sat=None, du=None, max_iter=100,
         exit_condition=None, warm_start=True, qp_mode="qp", count=None, trace=None):
-    """Receding-horizon loop restating mpc.py:128-304 for measure_freq == 1, streaming == False,
+    """Receding-horizon loop restating mpc.py:128-304 for streaming == False (any clock.measure_freq),
     with ``quad_program`` being the Riccati solver above (qp_mode "qp") or the lqr.py restatement
     (qp_mode "lqr").  Keeps the quirks: u_prev from U_ref at steps 0 and 1 (:185), applied control
     U_opt[:,0] (:250), target window lag (:276-277), exit codes 0/1/3 and the dropped last entry
@@ -557,10 +564,19 @@ def mpc(x0, dim_u, order, X_targ, U_targ, clock, experiment, model, Q, R, Qf, sa
         if exit_code > 0:
             break
         us[step] = U_opt[:, 0]
-        ts_step = clock.ts_step(step)
-        held = us[step]
-        res = experiment.simulate(xs[step], ts_step, lambda t, _u=held: _u)
-        xs[step + 1] = res[:, -1]
+        mf = clock.measure_freq
+        if (step + 1) % mf == 0:
+            # measure: re-simulate from the last measured state over the last mf intervals (mpc.py:252-260).
+            # NB the held controls are stacked newest first (:257) against an increasing time grid: replayed reversed.
+            ts_step = clock.ts_step(step)
+            us_step = np.vstack([us[step - jq] for jq in range(mf)] + [us[step]]).T
+            res = experiment.simulate(xs[step + 1 - mf], ts_step, us_step)
+            xs[step + 1] = res[:, -1]
+        else:
+            # close the loop with the model (mpc.py:261-267)
+            lx = np.reshape(experiment.lift(xs[step]), (-1, 1))
+            lu = wm.lift_u(us[step].reshape(-1, 1))
+            xs[step + 1] = np.reshape(experiment.proj(model.predict(lx, krtimes(lu, lx))), -1)
         X_guess = shift_guess(X_guess)
         U_guess = shift_guess(U_guess)
         X_ref = np.atleast_2d(X_targ[:, step:step + T + 1])
@@ -580,7 +596,7 @@ def mpc(x0, dim_u, order, X_targ, U_targ, clock, experiment, model, Q, R, Qf, sa
 
 
 def mpc_batch(x0s, A_models, dim_u, order, X_targ, U_targ, dt, horizon, n_steps, H0s, H_list, Q, R, Qf,
-              sat, du, max_iter=100, warm_start=True, qp_mode="qp", trace=None, generator_plant=False):
+              sat, du, max_iter=100, warm_start=True, qp_mode="qp", trace=None, generator_plant=False, measure_freq=1):
     """Loop ``mpc`` over an ensemble.  x0s (B, n); A_models (B or 1, n, n(1+P)); H0s (B or 1, d, d).
     Returns xs (B, n, n_steps+1) (NaN-padded after an early exit), us (B, m, n_steps),
     exit codes (B,), QP solves per MPC step (B, n_steps)."""
@@ -601,6 +617,7 @@ def mpc_batch(x0s, A_models, dim_u, order, X_targ, U_targ, dt, horizon, n_steps,
         U_t = U_targ[b] if np.ndim(U_targ) == 3 else U_targ
         exp = (OracleLExperiment if generator_plant else OracleQExperiment)(H0s[b if H0s.shape[0] > 1 else 0], list(Hl))
         clock = OracleClock(dt, horizon, n_steps)
+        clock.measure_freq = measure_freq
         cnt = []
         tr = [] if trace is not None else None
         (xs, us), _, code = mpc(x0s[b], dim_u, order, X_t, U_t, clock, exp, model, Q, R, Qf, sat=sat, du=du,

@@ -646,6 +646,41 @@ def test_mpc_crosstalk_model_on_reduced_states():
     assert rel(us, uo) <= 1e-5 and rel(xs, xo) <= 1e-5
 
 
+@pytest.mark.parametrize("path", ["real", "complex"])
+@pytest.mark.parametrize("cfg,mf", [(1, 5), (3, 3)])
+def test_measure_freq(cfg, mf, path):
+    """clock.measure_freq > 1 (reference test_NOT_state_freq, tests/test_mpc4quantum.py:705-804): the plant is measured
+    every mf-th step by re-simulating from the last measured state with the held controls replayed in the order
+    mpc.py:257 stacks them; the model closes the loop in between (mpc.py:252-267)."""
+    p = configs.build(cfg, batch=3, horizon=10 if cfg == 3 else None, n_steps=11)
+    clock = m4q.StepClock(p["dt"], p["horizon"], p["n_steps"])
+    clock.measure_freq = mf
+    models = p["models"]
+    res = m4q.mpc_batch(p["x0"], models, p["dim_u"], p["order"], p["X_targ"], p["U_targ"], clock, p["plant_op0"], p["plant_ops"],
+                        p["Q"], p["R"], p["Qf"], p["sat"], p["du"], force_complex=(path == "complex"))
+    xs, us, codes, solves = orc.mpc_batch(p["x0"], models, p["dim_u"], p["order"], p["X_targ"], p["U_targ"], p["dt"],
+                                          p["horizon"], p["n_steps"], p["plant_op0"], list(p["plant_ops"][0]), p["Q"], p["R"],
+                                          p["Qf"], p["sat"], p["du"], measure_freq=mf)
+    assert np.array_equal(res["qp_solves"], solves)
+    k = 2 * mf
+    assert rel(res["us"][:, :, :k], us[:, :, :k]) <= 1e-8 and rel(res["xs"][:, :, :k + 1], xs[:, :, :k + 1]) <= 1e-8
+    assert rel(res["us"], us) <= 1e-4 and rel(res["xs"], xs) <= 1e-4
+
+
+def test_mpc_dropin_measure_freq_host_plant_equals_fused():
+    p = configs.build(1, batch=1)
+    model = m4q.DMDc(4, 4, 4, p["models"][0])
+    outs = []
+    for exp in (m4q.QExperiment(p["plant_op0"][0], list(p["plant_ops"][0])), orc.OracleQExperiment(p["plant_op0"][0], list(p["plant_ops"][0]))):
+        clock = m4q.StepClock(p["dt"], p["horizon"], 10)
+        clock.measure_freq = 5
+        (xs, us), _, code = m4q.mpc(p["x0"][0], 1, 1, p["X_targ"], p["U_targ"], clock, exp, model, p["Q"], p["R"], p["Qf"],
+                                    sat=p["sat"], du=p["du"], progress_bar=False)
+        outs.append((xs, us, code))
+    assert outs[0][2] == outs[1][2] == 0
+    assert rel(outs[0][0], outs[1][0]) <= 1e-8 and rel(outs[0][1], outs[1][1]) <= 1e-8
+
+
 def test_exit_code_3_on_nonfinite_model():
     p = configs.build(2, batch=5)
     models = np.repeat(p["models"], 5, axis=0)

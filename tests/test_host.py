@@ -166,7 +166,7 @@ def test_problem_struct_layout_matches_header():
     body = header[header.index("typedef struct m4q_problem {"):header.index("} m4q_problem;")]
     fields = re.findall(r"^\s*(int32_t|double)\s+(\w+);", body, re.M)
     assert [f for _, f in fields] == [f for f, _ in _lib.Problem._fields_]
-    assert ctypes.sizeof(_lib.Problem) == 14 * 4 + 4 * 8
+    assert ctypes.sizeof(_lib.Problem) == 16 * 4 + 4 * 8
 
 
 def test_supported_shapes():
