@@ -52,7 +52,7 @@ __device__ __forceinline__ void stage_model(S* dst, const S* src, int jj) {
     const int pk = e - i * W;
     const int p = pk / NX;
     const int k = pk - p * NX;
-    dst[(p * NX + i) * PITCH + k] = src[e];
+    dst[ModelPitch<NX>::at(p, i, k)] = src[e];
   }
 }
 

@@ -95,9 +95,15 @@ struct Poly {
 
 template <int NX>
 struct ModelPitch {
-  // row pitch (in elements) of a model block in LDS: 16 -> 17 keeps the row-owner
-  // reads (lane stride = pitch elements) off a single bank
-  static constexpr int value = (NX % 16 == 0) ? NX + 1 : NX;
+  // Row pitch (in elements) of a model block in LDS.  Both access patterns must stay off a single bank:
+  // column owners (lane j reads [r][j]) and row owners (lane r reads [r][k], lane stride = one row).
+  // n = 4, 9: pitch n is conflict-free as is.  n = 16: a row is a multiple of the bank period; instead of
+  // padding (17, which costs d=4 a workgroup per CU) the column is XOR-swizzled with the row.
+  static constexpr int value = NX;
+  static __device__ __forceinline__ int at(int blk, int r, int k) {
+    if constexpr (NX == 16) return (blk * NX + r) * NX + (k ^ r);
+    else return (blk * NX + r) * NX + k;
+  }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -177,9 +183,9 @@ struct FusedProv {
     po.eval(l.u);
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      S a = mdl[i * PITCH + j];
+      S a = mdl[ModelPitch<NX>::at(0, i, j)];
 #pragma unroll
-      for (int p = 0; p < NP; ++p) cmac_r(a, mdl[((1 + p) * NX + i) * PITCH + j], po.pu[p]);
+      for (int p = 0; p < NP; ++p) cmac_r(a, mdl[ModelPitch<NX>::at(1 + p, i, j)], po.pu[p]);
       Ac[i] = a;
     }
   }
@@ -193,13 +199,13 @@ struct FusedProv {
       //   av = sum_k lane_k(v) A_t[j][k],   nx[p] = sum_k lane_k(xg) N_p[j][k]
       S arow[NX];
 #pragma unroll
-      for (int k = 0; k < NX; ++k) arow[k] = mdl[j * PITCH + k];
+      for (int k = 0; k < NX; ++k) arow[k] = mdl[ModelPitch<NX>::at(0, j, k)];
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         S nrow[NX];
 #pragma unroll
         for (int k = 0; k < NX; ++k) {
-          nrow[k] = mdl[((1 + p) * NX + j) * PITCH + k];
+          nrow[k] = mdl[ModelPitch<NX>::at(1 + p, j, k)];
           cmac_r(arow[k], nrow[k], po.pu[p]);
         }
         nx[p] = dot_lane_index<false, false, NX>(l.xg, nrow);
@@ -213,10 +219,10 @@ struct FusedProv {
       static_for<0, NX>([&](auto kk) {
         constexpr int k = decltype(kk)::value;
         S own[NP + 1];
-        own[NP] = mdl[j * PITCH + k];
+        own[NP] = mdl[ModelPitch<NX>::at(0, j, k)];
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-          own[p] = mdl[((1 + p) * NX + j) * PITCH + k];
+          own[p] = mdl[ModelPitch<NX>::at(1 + p, j, k)];
           cmac_r(own[NP], own[p], po.pu[p]);
         }
         emit_terms<IdxSameLaneVec<k>, false, false, false, 0, NP + 1>(accs, srcs, own);
