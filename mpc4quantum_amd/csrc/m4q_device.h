@@ -122,12 +122,15 @@ __device__ __forceinline__ void static_for(F&& f) {
 // asm string (cdna_hip_programming.md 5.7 item 2): every asm statement opens with `s_nop 1`; the
 // multi-term statements of m4q_dpp_gen.h pay it once per 8-16 FMAs.
 #define M4Q_DPP " row_mask:0xf bank_mask:0xf\n\t"
+#ifndef M4Q_NOP
+#define M4Q_NOP "s_nop 1\n\t"
+#endif
 
 #ifndef M4Q_BCAST_SHFL
 template <int K>
 __device__ __forceinline__ double bcast(double x) {
   double r;
-  asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2" M4Q_DPP : "=v"(r) : "v"(x), "n"(K));
+  asm(M4Q_NOP "v_mov_b64_dpp %0, %1 row_newbcast:%2" M4Q_DPP : "=v"(r) : "v"(x), "n"(K));
   return r;
 }
 #else

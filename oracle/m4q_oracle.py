@@ -28,7 +28,7 @@ from scipy.linalg import expm as _expm
 __all__ = [
     "multinomial_powers", "create_power_list", "size_of_library", "monomials", "diff_tables",
     "krtimes", "discretize_homogeneous", "vectorize_me", "liouvillian_ij",
-    "OracleWrapModel", "OracleDMDc", "lqr_quad_program", "quad_program", "kkt_quad_program",
+    "OracleWrapModel", "OracleDMDc", "lqr_quad_program", "quad_program", "kkt_quad_program", "exact_quad_program",
     "iqp_line_search", "shift_guess", "OracleClock", "OracleQExperiment", "plant_step",
     "mpc", "mpc_batch",
 ]
@@ -357,6 +357,69 @@ def kkt_quad_program(x_init, X_bm, U_bm, Q_ls, R_ls, A_ls, B_ls, Delta_ls):
         X[:, t] = seg[:n] + 1j * seg[n:]
     U = sol[nx:nx + nu].reshape(T, m).T
     return X, U
+
+
+def exact_quad_program(x_init, X_bm, U_bm, Q_ls, R_ls, A_ls, B_ls, Delta_ls, u_prev=None, sat=None, du=None):
+    """The box-constrained QP of optimize.quad_program (optimize.py:27-43,54) solved EXACTLY on the CPU: the
+    states are condensed out and the bounded linear least-squares problem in the controls goes to
+    scipy.optimize.lsq_linear (BVLS active set).  Reference point for the next-tier device solver:
+    the shipped Riccati path clips instead, which is sub-optimal when a bound is active."""
+    from scipy.linalg import sqrtm
+    from scipy.optimize import lsq_linear
+    m, T = U_bm.shape
+    n = X_bm.shape[0]
+    X_bm = np.asarray(X_bm, dtype=complex)
+    U_bm = np.asarray(U_bm, dtype=float)
+    lo = -sat * np.ones((T, m))
+    hi = sat * np.ones((T, m))
+    if u_prev is not None and du is not None:
+        up = np.reshape(u_prev, -1).real
+        lo[0], hi[0] = np.maximum(lo[0], up - du), np.minimum(hi[0], up + du)
+
+    def c2r(M):
+        M = np.asarray(M, dtype=complex)
+        return np.block([[M.real, -M.imag], [M.imag, M.real]])
+
+    def v2r(v):
+        v = np.asarray(v, dtype=complex).reshape(-1)
+        return np.concatenate([v.real, v.imag])
+    free = [np.asarray(x_init, dtype=complex).reshape(-1)]
+    for t in range(T):
+        free.append(A_ls[t] @ free[-1] + np.reshape(Delta_ls[t], -1))
+    Phi = np.zeros((T + 1, n, T * m), dtype=complex)
+    for s_ in range(T):
+        for k in range(m):
+            v = np.asarray(B_ls[s_], dtype=complex)[:, k]
+            Phi[s_ + 1, :, s_ * m + k] = v
+            for t in range(s_ + 1, T):
+                v = A_ls[t] @ v
+                Phi[t + 1, :, s_ * m + k] = v
+    rows, rhs = [], []
+    for t in range(T + 1):
+        Wq = np.real(sqrtm(c2r(Q_ls[t])))
+        rows.append(Wq @ np.vstack([Phi[t].real, Phi[t].imag]))
+        rhs.append(Wq @ (v2r(X_bm[:, t]) - v2r(free[t])))
+    for t in range(T):
+        Wr = np.real(sqrtm(np.asarray(R_ls[t]).real))
+        E = np.zeros((m, T * m))
+        E[:, t * m:(t + 1) * m] = np.identity(m)
+        rows.append(Wr @ E)
+        rhs.append(Wr @ U_bm[:, t])
+    res = lsq_linear(np.vstack(rows), np.concatenate(rhs), bounds=(lo.reshape(-1), hi.reshape(-1)), method='bvls', tol=1e-15,
+                     max_iter=5000)
+    U = res.x.reshape(T, m).T
+    X = np.zeros((n, T + 1), dtype=complex)
+    X[:, 0] = free[0]
+    cost = 0.0
+    for t in range(T):
+        X[:, t + 1] = A_ls[t] @ X[:, t] + B_ls[t] @ U[:, t] + np.reshape(Delta_ls[t], -1)
+    for t in range(T + 1):
+        e = X[:, t] - X_bm[:, t]
+        cost += (e.conj() @ Q_ls[t] @ e).real
+    for t in range(T):
+        e = U[:, t] - U_bm[:, t]
+        cost += (e @ R_ls[t] @ e).real
+    return X, U, float(cost)
 
 
 # --------------------------------------------------------------------------------------------

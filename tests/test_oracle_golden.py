@@ -117,3 +117,27 @@ def test_lqr_quad_program(golden, name, order, tag):
     assert abs(cost - float(g[k2 + "_cost"])) <= 1e-10 * max(1.0, abs(cost))
     if tag == "sat":
         assert np.isclose(np.abs(U).max(), float(g[k2 + "_sat"]))     # the bound is active in this fixture
+
+
+def test_clipped_riccati_vs_exact_box_qp():
+    """Quantifies the documented difference (DESIGN.md 2.1): with no bound active the Riccati path IS the QP solution;
+    with bounds active it is feasible and its cost is above the exact optimum (scipy BVLS on the condensed problem)."""
+    from mpc4quantum_amd import configs
+    p = configs.build(1, batch=1)
+    n, m, T = 4, 1, p["horizon"]
+    mdl = p["models"][0]
+    wm = orc.OracleWrapModel(mdl[:, :n], mdl[:, n:], m, 1)
+    rng = np.random.default_rng(3)
+    Xg = np.tile(p["x0"][0][:, None], (1, T + 1))
+    Ug = 0.3 * p["sat"] * rng.uniform(-1, 1, (m, T))
+    A_ls, B_ls, D_ls = wm.get_model_along_traj(Xg, Ug, np.arange(T))
+    X_bm, U_bm = p["X_targ"][:, :T + 1], p["U_targ"][:, :T]
+    Q_ls, R_ls = [p["Q"]] * T + [p["Qf"]], [p["R"]] * T
+    for sat, active in ((1e3, False), (p["sat"], True)):
+        Xc, Uc, cc, _ = orc.quad_program(Xg[:, 0], X_bm, U_bm, Q_ls, R_ls, A_ls, B_ls, D_ls, None, sat, None)
+        Xe, Ue, ce = orc.exact_quad_program(Xg[:, 0], X_bm, U_bm, Q_ls, R_ls, A_ls, B_ls, D_ls, None, sat, None)
+        assert np.abs(Ue).max() <= sat * (1 + 1e-12)
+        if not active:
+            assert np.abs(Uc - Ue).max() < 1e-8 and abs(cc - ce) < 1e-8 * max(1, ce)
+        else:
+            assert np.isclose(np.abs(Ue).max(), sat) and cc >= ce - 1e-9 and np.abs(Uc - Ue).max() > 1e-3
