@@ -46,6 +46,9 @@ extern "C" {
 /* qp_flags */
 #define M4Q_QP_REF_LQR 1 /* reproduce mpc4quantum/lqr.py:14-79 as written (no Delta, no du band) */
 #define M4Q_QP_DU_BAND 2 /* also clip the first control to u_prev +- du (optimize.py:29-30) */
+#define M4Q_QP_EXACT_BOX 4 /* solve the box-constrained QP of optimize.py:27-54 to optimality (projected Newton on the
+                              Riccati factorisation) instead of clipping the unconstrained rollout; m4q_quad_program_batch
+                              only, not with M4Q_QP_REF_LQR */
 
 /* plant_kind */
 #define M4Q_PLANT_NONE 0        /* caller supplies xs[step+1] between m4q_session_run calls */

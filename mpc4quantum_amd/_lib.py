@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libm4q_hip.so")
 
 QP_REF_LQR = 1
 QP_DU_BAND = 2
+QP_EXACT_BOX = 4
 OPT_FORCE_COMPLEX = 1
 PLANT_NONE, PLANT_HAMILTONIAN, PLANT_GENERATOR = 0, 1, 2
 E_UNSUPPORTED, E_BADARG, E_NODEVICE = -1001, -1002, -1003

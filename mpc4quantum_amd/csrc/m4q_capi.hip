@@ -627,13 +627,15 @@ int m4q_quad_program_batch(int32_t B, int32_t dim_x, int32_t dim_u, int32_t T, i
   if (B <= 0 || T <= 0 || !x_init || !X_bm || !U_bm || !Q_ls || !R_ls || !A_ls || !B_ls || !X_opt || !U_opt || !cost)
     return fail(M4Q_E_BADARG, "m4q_quad_program_batch: bad argument");
   if (!(sat > 0)) return fail(M4Q_E_BADARG, "sat must be positive");
+  if ((qp_flags & M4Q_QP_EXACT_BOX) && (qp_flags & M4Q_QP_REF_LQR))
+    return fail(M4Q_E_BADARG, "M4Q_QP_EXACT_BOX cannot be combined with M4Q_QP_REF_LQR");
   int rc = need_device();
   if (rc) return rc;
   const size_t n = dim_x, m = dim_u, C = 16;
   Tmp t;
   m4q::QpArgs a{};
   a.B = B; a.T = T; a.flags = qp_flags; a.sat = sat; a.du = du;
-  void *d_x, *d_xb, *d_ub, *d_q, *d_r, *d_a, *d_b, *d_d = nullptr, *d_up = nullptr, *d_xo, *d_uo, *d_c, *d_g;
+  void *d_x, *d_xb, *d_ub, *d_q, *d_r, *d_a, *d_b, *d_d = nullptr, *d_up = nullptr, *d_xo, *d_uo, *d_c, *d_g, *d_it = nullptr;
   if ((rc = t.up(x_init, (size_t)B * n * C, &d_x))) return rc;
   if ((rc = t.up(X_bm, (bm_per_instance ? B : 1) * (size_t)(T + 1) * n * C, &d_xb))) return rc;
   if ((rc = t.up(U_bm, (bm_per_instance ? B : 1) * (size_t)T * m * 8, &d_ub))) return rc;
@@ -653,9 +655,29 @@ int m4q_quad_program_batch(int32_t B, int32_t dim_x, int32_t dim_u, int32_t T, i
   a.Q_ls = (const cplx*)d_q; a.R_ls = (const cplx*)d_r;
   a.A_ls = (const cplx*)d_a; a.B_ls = (const cplx*)d_b; a.D_ls = (const cplx*)d_d; a.u_prev = (const double*)d_up;
   a.X_opt = (cplx*)d_xo; a.U_opt = (double*)d_uo; a.cost = (double*)d_c; a.gains = (cplx*)d_g;
+  if (qp_flags & M4Q_QP_EXACT_BOX) {
+    void *d_xa, *d_ua, *d_st, *d_un;
+    if ((rc = t.up(nullptr, (size_t)B * (T + 1) * n * C, &d_xa))) return rc;
+    if ((rc = t.up(nullptr, (size_t)B * T * m * 8, &d_ua))) return rc;
+    if ((rc = t.up(nullptr, (size_t)B * T * m * 8, &d_st))) return rc;
+    if ((rc = t.up(nullptr, (size_t)B * T * m * 8, &d_un))) return rc;
+    a.X_alt = (cplx*)d_xa; a.U_alt = (double*)d_ua; a.pin_stat = (double*)d_st; a.U_newton = (double*)d_un;
+    if (getenv("M4Q_QP_TRACE")) {
+      if ((rc = t.up(nullptr, (size_t)B * 4, &d_it))) return rc;
+      a.newton_iters = (int*)d_it;
+    }
+  }
   rc = sh->launch_qp(a, nullptr);
   if (rc) return fail(rc, "qp launch failed");
   HIP_TRY(hipDeviceSynchronize());
+  if (d_it) {                                             // diagnostic: Newton iterations per instance
+    std::vector<int> it(B);
+    if ((rc = down(it.data(), d_it, (size_t)B * 4))) return rc;
+    long sum = 0;
+    int mx = 0;
+    for (int v : it) { sum += v; mx = v > mx ? v : mx; }
+    fprintf(stderr, "m4q: exact box QP: %d instances, Newton iterations mean %.2f max %d\n", B, (double)sum / B, mx);
+  }
   if ((rc = down(X_opt, d_xo, (size_t)B * (T + 1) * n * C))) return rc;
   if ((rc = down(U_opt, d_uo, (size_t)B * T * m * 8))) return rc;
   if ((rc = down(cost, d_c, (size_t)B * 8))) return rc;

@@ -519,8 +519,28 @@ __global__ __launch_bounds__(64) M4Q_OCC void qp_kernel(QpArgs a) {
     const cplx x0 = a.x_init[b * NX + j];
     const double obj = rollout_forward<cplx, NX, NU, true>(prov, T, x0, win, cost, a.flags, gains, a.sat, lo0, hi0, Xo, Uo, j, st,
                                                               u_first);
-    if (valid && jj == 0) a.cost[b] = obj;
     wave_sync();
+    double obj_out = obj;
+    if (a.flags & QP_EXACT_BOX) {
+      const GView Xb = gview(a.X_alt, q0 * sX, gl * sX);
+      const GView Ub = gview(a.U_alt, q0 * sU, gl * sU);
+      const GView stat = gview(a.pin_stat, q0 * sU, gl * sU);
+      const GView Un = gview(a.U_newton, q0 * sU, gl * sU);
+      Box box;
+      box.sat = a.sat;
+      bool in_a;
+      int n_newton;
+      obj_out = solve_box_qp<cplx, NX, NU>(prov, T, x0, win, cost, a.flags, gains, box, lo0, hi0, Xo, Uo, Xb, Ub, stat, Un, obj,
+                                           valid, j, L.lane_ok, in_a, n_newton);
+      if (!in_a && st) {                                  // the answer sits in the alternate pair
+        for (int t = 0; t <= T; ++t) Xo.st<cplx>(t * NX + j, Xb.ld<cplx>(t * NX + j));
+        if (j == 0)
+          for (int i = 0; i < T * NU; ++i) Uo.st<double>(i, Ub.ld<double>(i));
+      }
+      if (valid && jj == 0 && a.newton_iters) a.newton_iters[b] = n_newton;
+      wave_sync();
+    }
+    if (valid && jj == 0) a.cost[b] = obj_out;
   }
 }
 

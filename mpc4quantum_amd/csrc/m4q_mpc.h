@@ -14,6 +14,7 @@ namespace m4q {
 enum : int {
   QP_REF_LQR = 1,   // reproduce lqr.py as written (no Delta, xbar_{t+1}==xbar_t, cost built on xbar, absolute cost)
   QP_DU_BAND = 2,   // clip the first control to u_prev +- du as well (optimize.py:29-30)
+  QP_EXACT_BOX = 4, // solve the box-constrained QP to optimality (projected Newton) instead of clipping the Riccati rollout
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -305,13 +306,24 @@ __device__ __forceinline__ S qrow_times(const S* Qt, S v, int j) {
 //   P  <- Q + Kx^H R Kx + Sx^H P Sx ;  p <- -Q r + Kx^H R k + Sx^H (P s + p)   lqr.py:64-65
 // gains layout: [t][col 0..NX][NU]  (col NX holds k); the view is positioned at the instance.
 // ---------------------------------------------------------------------------------------------
+#ifndef M4Q_NO_PHASE
 #define M4Q_PHASE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define M4Q_PHASE() ((void)0)
+#endif
 // keeps loop-invariant LDS/global loads inside the horizon loops (hoisted, they cost hundreds of VGPRs)
 #define M4Q_NO_HOIST() asm volatile("" ::: "memory")
 
-template <class S, int NX, int NU, class Prov>
+// Working set of the exact box-QP solver (projected Newton, see solve_box_qp): stat [T][NU] doubles
+// (0 free, +-1 pinned at the upper/lower bound), Uk [T][NU] the current feasible iterate.
+struct PinCtx {
+  GView stat;
+  GView Uk;
+};
+
+template <class S, int NX, int NU, class Prov, bool PINNED = false>
 __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const Window& win, const CostRef<S>& cost, int flags,
-                                                  const GView& gains, int j, bool store_ok) {
+                                                  const GView& gains, int j, bool store_ok, const PinCtx* pin = nullptr) {
   const bool ref = (flags & QP_REF_LQR) != 0;
   S Pc[NX];
   S pv = zero_of<S>();
@@ -372,13 +384,40 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
       }
       h[k] = rowsum<NX>(cmul(cconj(Brow[k]), w));
     }
-    herm_inverse<NU>(g, ginv);
-    M4Q_PHASE();
-
     // Hh[l] = (B^H P A_t)[l][j] = sum_i BhP[l][i] A_t[i][j]
     S Hh[NU];
 #pragma unroll
     for (int l = 0; l < NU; ++l) Hh[l] = dot_lane_index<false, false, NX>(BhP[l], Ac);
+    bool fix[NU];
+    double dufix[NU];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) { fix[k] = false; dufix[k] = 0.0; }
+    if constexpr (PINNED) {
+      // controls pinned at a bound are constants of the stage: K row = [0 | du_fix]; the free ones respond to them:
+      //   G_ff du_f = -(H_f dx + h_f + G_fp du_p)
+#pragma unroll
+      for (int k = 0; k < NU; ++k) {
+        fix[k] = pin->stat.template ld<double>(t * NU + k) != 0.0;
+        dufix[k] = fix[k] ? pin->Uk.template ld<double>(t * NU + k) - ub[k] : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < NU; ++k) {
+#pragma unroll
+        for (int l = 0; l < NU; ++l) {
+          const cplx gkl = k <= l ? g[k][l] : cconj(g[l][k]);
+          cmac_r(h[k], from_cplx<S>(gkl), dufix[l]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NU; ++k) {
+#pragma unroll
+        for (int l = k; l < NU; ++l)
+          if (fix[k] || fix[l]) g[k][l] = mk(k == l ? 1.0 : 0.0, 0.0);
+        if (fix[k]) { Hh[k] = zero_of<S>(); h[k] = zero_of<S>(); }
+      }
+    }
+    herm_inverse<NU>(g, ginv);
+    M4Q_PHASE();
     S Kx[NU], kk[NU];
 #pragma unroll
     for (int k = 0; k < NU; ++k) {
@@ -389,7 +428,7 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
         cmac(b, from_cplx<S>(ginv[k][l]), h[l]);
       }
       Kx[k] = cneg(a);
-      kk[k] = cneg(b);
+      kk[k] = fix[k] ? from_real<S>(dufix[k]) : cneg(b);
     }
     if (store_ok) {
       const unsigned gt = (unsigned)t * (NX + 1) * NU;
@@ -570,6 +609,189 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
     }
   }
   return rowsum<NX>(cx) + cu;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exact box-constrained QP (the statement of optimize.quad_program, optimize.py:27-43,54, which the live reference
+// hands to OSQP): projected Newton (Bertsekas 1982) on the Riccati factorisation.
+//   iterate  u^k feasible (start: the clipped Riccati rollout);
+//   1. adjoint sweep -> gradient g = dJ/du at u^k; a control sitting on a bound with the gradient pushing outward
+//      is pinned, everything else is free;
+//   2. Riccati sweep with the pinned controls held (riccati_backward<PINNED>) = Newton step for the free ones;
+//   3. closed-loop unclipped rollout -> Newton point u_N; projection arc u(a) = clip(u^k + a (u_N - u^k)), a = 1, 1/2, ...
+//      accepted at the first decrease of the objective (open-loop rollouts).
+// Terminates when the Newton point is the iterate (then the KKT conditions hold) or nothing decreases.
+// ---------------------------------------------------------------------------------------------
+struct Box {       // |u| <= sat, first control also within [lo0, hi0]
+  double sat;
+  template <int NU>
+  __device__ __forceinline__ void at(int t, int k, const double (&lo0)[NU], const double (&hi0)[NU], double& lo, double& hi) const {
+    lo = -sat;
+    hi = sat;
+    if (t == 0) { lo = fmax(lo, lo0[k]); hi = fmin(hi, hi0[k]); }
+  }
+};
+
+// gradient of the objective at (Xk, Uk) and the working set.  Returns the number of pinned controls (replicated).
+template <class S, int NX, int NU, class Prov>
+__device__ __forceinline__ int adjoint_working_set(const Prov& prov, int T, const Window& win, const CostRef<S>& cost, const GView& Xk,
+                                                    const GView& Uk, const Box& box, const double (&lo0)[NU],
+                                                    const double (&hi0)[NU], const GView& stat, int j, bool store_ok) {
+  // lam = Q_T e_T ;  g_t = 2 (R (u_t - ub_t) + Re B_t^H lam_{t+1}) ;  lam_t = Q_t e_t + A_t^H lam_{t+1}
+  S lam = qrow_times<NX>(cost.q(T, T), csub(Xk.ld<S>(T * NX + j), win.xbm.ld<S>(T * NX + j)), j);
+  int npin = 0;
+  for (int t = T - 1; t >= 0; --t) {
+    M4Q_NO_HOIST();
+    const typename Prov::Lin lin = prov.fetch(t);
+    S Ac[NX];
+    prov.col(lin, Ac);
+    S av, Brow[NU], dlt;
+    prov.rows(lin, lam, av, Brow, dlt);
+    const S* Rt = cost.r(t);
+    double u[NU], ub[NU];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) { u[k] = Uk.ld<double>(t * NU + k); ub[k] = win.ubm.ld<double>(t * NU + k); }
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+      double gk = rowsum<NX>(real_of(cmul(cconj(Brow[k]), lam)));
+#pragma unroll
+      for (int l = 0; l < NU; ++l) gk = fma(real_of(Rt[k * NU + l]), u[l] - ub[l], gk);
+      double lo, hi;
+      box.at<NU>(t, k, lo0, hi0, lo, hi);
+      const double eps = 1e-12 * box.sat;
+      double st = 0.0;
+      if (u[k] <= lo + eps && gk > 0.0) st = -1.0;
+      if (u[k] >= hi - eps && gk < 0.0) st = 1.0;
+      if (hi - lo <= 2 * eps) st = 1.0;                  // degenerate interval: nothing to optimise
+      npin += st != 0.0 ? 1 : 0;
+      if (store_ok && j == 0) stat.st<double>(t * NU + k, st);
+    }
+    const S e = csub(Xk.ld<S>(t * NX + j), win.xbm.ld<S>(t * NX + j));
+    lam = dot_lane_index<false, true, NX>(lam, Ac, qrow_times<NX>(cost.q(t, T), e, j));     // Q_t e_t + A_t^H lam
+  }
+  return npin;
+}
+
+// closed-loop rollout of the Newton policy WITHOUT clipping (pinned controls keep their value): writes u_N,
+// returns max |u_N - u^k| (replicated).
+template <class S, int NX, int NU, class Prov>
+__device__ __forceinline__ double rollout_newton(const Prov& prov, int T, S x0, const Window& win, int flags, const GView& gains,
+                                                 const PinCtx& pin, const GView& Un, int j, bool store_ok) {
+  S x = x0;
+  double dmax = 0.0;
+  for (int t = 0; t < T; ++t) {
+    M4Q_NO_HOIST();
+    const typename Prov::Lin lin = prov.fetch(t);
+    S ax, Brow[NU], dlt;
+    prov.rows(lin, x, ax, Brow, dlt);
+    const S dx = csub(x, win.xbm.ld<S>(t * NX + j));
+    const unsigned gt = (unsigned)t * (NX + 1) * NU;
+    S xn = cadd(ax, dlt);
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+      const double uk = pin.Uk.ld<double>(t * NU + k);
+      const bool fixd = pin.stat.ld<double>(t * NU + k) != 0.0;
+      const double part = real_of(cmul(gains.ld<S>(gt + j * NU + k), dx));
+      double un = rowsum<NX>(part) + real_of(gains.ld<S>(gt + NX * NU + k)) + win.ubm.ld<double>(t * NU + k);
+      un = fixd ? uk : un;
+      dmax = fmax(dmax, fabs(un - uk));
+      if (store_ok && j == 0) Un.st<double>(t * NU + k, un);
+      cmac_r(xn, Brow[k], un);
+    }
+    x = xn;
+  }
+  return dmax;
+}
+
+// open-loop rollout of u = clip(u^k + alpha (u_N - u^k)) with the objective of optimize.py:33-34,54; writes (Xc, Uc).
+template <class S, int NX, int NU, class Prov>
+__device__ __forceinline__ double rollout_arc(const Prov& prov, int T, S x0, const Window& win, const CostRef<S>& cost,
+                                              const GView& Uk, const GView& Un, double alpha, const Box& box,
+                                              const double (&lo0)[NU], const double (&hi0)[NU], const GView& Xc, const GView& Uc,
+                                              int j, bool store_ok) {
+  S x = x0;
+  if (store_ok) Xc.st<S>(j, x);
+  double cx = 0.0, cu = 0.0;
+  for (int t = 0; t < T; ++t) {
+    M4Q_NO_HOIST();
+    const typename Prov::Lin lin = prov.fetch(t);
+    S ax, Brow[NU], dlt;
+    prov.rows(lin, x, ax, Brow, dlt);
+    const S e = csub(x, win.xbm.ld<S>(t * NX + j));
+    cx += dot_re(e, qrow_times<NX>(cost.q(t, T), e, j));
+    const S* Rt = cost.r(t);
+    double u[NU], eu[NU];
+    S xn = cadd(ax, dlt);
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+      const double uk = Uk.ld<double>(t * NU + k), un = Un.ld<double>(t * NU + k);
+      double lo, hi;
+      box.at<NU>(t, k, lo0, hi0, lo, hi);
+      u[k] = fmin(fmax(fma(alpha, un - uk, uk), lo), hi);
+      eu[k] = u[k] - win.ubm.ld<double>(t * NU + k);
+      cmac_r(xn, Brow[k], u[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < NU; ++k)
+#pragma unroll
+      for (int l = 0; l < NU; ++l) cu = fma(eu[k] * real_of(Rt[k * NU + l]), eu[l], cu);
+    x = xn;
+    if (store_ok) {
+      Xc.st<S>((t + 1) * NX + j, x);
+      if (j == 0) {
+#pragma unroll
+        for (int k = 0; k < NU; ++k) Uc.st<double>(t * NU + k, u[k]);
+      }
+    }
+  }
+  const S e = csub(x, win.xbm.ld<S>(T * NX + j));
+  cx += dot_re(e, qrow_times<NX>(cost.q(T, T), e, j));
+  return rowsum<NX>(cx) + cu;
+}
+
+// The exact solve for the four rows of a wavefront.  On entry (Xa, Ua) hold the clipped Riccati rollout and Ja its
+// objective; the two buffer pairs (Xa, Ua) / (Xb, Ub) ping-pong, `cur_is_a` tells which one holds the answer on exit.
+// `act` marks the rows that take part.  Returns the objective of the answer.
+template <class S, int NX, int NU, class Prov>
+__device__ __forceinline__ double solve_box_qp(const Prov& prov, int T, S x0, const Window& win, const CostRef<S>& cost, int flags,
+                                               const GView& gains, const Box& box, const double (&lo0)[NU],
+                                               const double (&hi0)[NU], GView Xa, GView Ua, GView Xb, GView Ub, const GView& stat,
+                                               const GView& Un, double Ja, bool act, int j, bool lane_ok, bool& cur_is_a,
+                                               int& n_newton) {
+  bool going = act;
+  double Jk = Ja;
+  cur_is_a = true;
+  n_newton = 0;
+  for (int it = 0; it < 50 && __any(going); ++it) {
+    const GView Xk = cur_is_a ? Xa : Xb, Uk = cur_is_a ? Ua : Ub;
+    const GView Xc = cur_is_a ? Xb : Xa, Uc = cur_is_a ? Ub : Ua;
+    const bool st = going && lane_ok;
+    adjoint_working_set<S, NX, NU>(prov, T, win, cost, Xk, Uk, box, lo0, hi0, stat, j, st);
+    wave_sync();
+    PinCtx pin;
+    pin.stat = stat;
+    pin.Uk = Uk;
+    riccati_backward<S, NX, NU, Prov, true>(prov, T, win, cost, flags, gains, j, st, &pin);
+    wave_sync();
+    const double dmax = rollout_newton<S, NX, NU>(prov, T, x0, win, flags, gains, pin, Un, j, st);
+    wave_sync();
+    if (going) ++n_newton;
+    if (!(dmax > 1e-13 * box.sat)) going = false;            // Newton point == iterate (or NaN): KKT point reached
+    // projection arc with backtracking
+    double alpha = 1.0;
+    bool searching = going;
+    bool accepted = false;
+    for (int ls = 0; ls < 30 && __any(searching); ++ls) {
+      const double Jc = rollout_arc<S, NX, NU>(prov, T, x0, win, cost, Uk, Un, alpha, box, lo0, hi0, Xc, Uc, j, searching && lane_ok);
+      wave_sync();
+      if (searching && Jc < Jk) { accepted = true; searching = false; Jk = Jc; }
+      alpha *= 0.5;
+    }
+    if (going && !accepted) going = false;                    // no decrease along the arc: the iterate stands
+    if (going) cur_is_a = !cur_is_a;
+    wave_sync();
+  }
+  return Jk;
 }
 
 // ---------------------------------------------------------------------------------------------

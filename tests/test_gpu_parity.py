@@ -217,6 +217,62 @@ def test_qp_mode_vs_independent_kkt():
         assert rel(X[b].T, Xk) <= 1e-8
 
 
+def _scenario_qp(config, order, T, Bn, seed, amp):
+    """Linearisation of a reference scenario's model along a perturbed guess: a Hermiticity-preserving LTV problem."""
+    rng = np.random.default_rng(seed)
+    p = configs.build(config, batch=Bn, order=order, horizon=T)
+    n, m = p["x0"].shape[1], p["U_targ"].shape[0]
+    A, Bm, D, x0 = [], [], [], []
+    for b in range(Bn):
+        mod = p["models"][b if p["models"].shape[0] > 1 else 0]
+        wm = orc.OracleWrapModel(mod[:, :n], mod[:, n:], m, order)
+        xg = np.tile(p["x0"][b][:, None], (1, T + 1))
+        ug = amp * p["sat"] * rng.uniform(-1, 1, (m, T))
+        Ao, Bo, Do = wm.get_model_along_traj(xg, ug, np.arange(T))
+        A.append(np.stack(Ao)); Bm.append(np.stack(Bo)); D.append(np.stack(Do).reshape(T, n)); x0.append(xg[:, 0])
+    Qs = np.stack([p["Q"]] * T + [p["Qf"]]).astype(complex)
+    Rs = np.stack([p["R"]] * T).astype(complex)
+    return (np.stack(x0), p["X_targ"][:, :T + 1].T[None], p["U_targ"][:, :T].T[None].real, Qs, Rs, np.stack(A), np.stack(Bm),
+            np.stack(D), p["sat"])
+
+
+@pytest.mark.parametrize("config,order,T,sat_scale,du", [(1, 1, 10, 1.0, None), (1, 2, 25, 0.3, None), (3, 2, 40, 0.3, None),
+                                                          (3, 2, 20, 0.3, 0.05), (3, 1, 12, 1e3, None), (4, 1, 20, 0.3, None)])
+def test_exact_box_qp_vs_bvls_oracle(config, order, T, sat_scale, du):
+    """M4Q_QP_EXACT_BOX: the box-constrained QP of optimize.py:27-54 solved to optimality on the device (projected Newton
+    on the Riccati factorisation) against an independent solver of the same statement (scipy BVLS on the condensed
+    problem) - tolerance 1e-9 of the bound on the controls, 1e-11 relative on the objective."""
+    Bn = 5
+    x0, Xb, Ub, Qs, Rs, A, Bm, D, sat = _scenario_qp(config, order, T, Bn, 40 + config, 0.3)
+    sat = sat * sat_scale
+    up = 0.02 * np.arange(Bn * Ub.shape[2]).reshape(Bn, -1) if du else None
+    X, U, cost, _ = m4q.quad_program_batch(x0, Xb, Ub, Qs, Rs, A, Bm, D, up, sat, du, exact=True)
+    Xc, Uc, costc, _ = m4q.quad_program_batch(x0, Xb, Ub, Qs, Rs, A, Bm, D, up, sat, du)
+    assert np.abs(U).max() <= sat
+    assert np.all(cost <= costc * (1 + 1e-14))                    # never worse than the clipped rollout it starts from
+    active = 0
+    for b in range(Bn):
+        Xe, Ue, ce = orc.exact_quad_program(x0[b], Xb[0].T, Ub[0].T, list(Qs), list(Rs), list(A[b]), list(Bm[b]), list(D[b]),
+                                            None if up is None else up[b], sat, du)
+        assert np.abs(U[b].T - Ue).max() <= 1e-9 * min(sat, 1.0)
+        assert rel(X[b].T, Xe) <= 1e-9
+        assert abs(cost[b] - ce) <= 1e-11 * max(1.0, abs(ce))
+        active += int((np.abs(Ue) >= sat * (1 - 1e-12)).sum())
+        if du:
+            assert np.all(np.abs(U[b, 0] - up[b]) <= du * (1 + 1e-14))
+    if sat_scale < 100:
+        assert active > 0 and np.abs(U - Uc).max() > 1e-4 * sat   # the bounds matter in these cases
+    else:
+        assert active == 0 and rel(U, Uc) <= 1e-12                # inactive: the clipped Riccati rollout is already optimal
+
+
+def test_exact_box_qp_rejects_ref_lqr():
+    rng = np.random.default_rng(1)
+    A, Bm, D, x0, Xb, Ub, Qs, Rs = _random_ltv(rng, 4, 1, 3, 1)
+    with pytest.raises(_lib.M4qError):
+        m4q.quad_program_batch(x0, Xb, Ub, Qs, Rs, A, Bm, D, None, 1.0, None, flags=_lib.QP_REF_LQR, exact=True)
+
+
 def test_quad_program_dropin_signature():
     """optimize.quad_program(x_init, X_bm, U_bm, Q_ls, R_ls, A_ls, B_ls, Delta_ls, u_prev, sat, du, verbose)."""
     rng = np.random.default_rng(9)
