@@ -47,8 +47,8 @@ extern "C" {
 #define M4Q_QP_REF_LQR 1 /* reproduce mpc4quantum/lqr.py:14-79 as written (no Delta, no du band) */
 #define M4Q_QP_DU_BAND 2 /* also clip the first control to u_prev +- du (optimize.py:29-30) */
 #define M4Q_QP_EXACT_BOX 4 /* solve the box-constrained QP of optimize.py:27-54 to optimality (projected Newton on the
-                              Riccati factorisation) instead of clipping the unconstrained rollout; m4q_quad_program_batch
-                              only, not with M4Q_QP_REF_LQR */
+                              Riccati factorisation) instead of clipping the unconstrained rollout; not with
+                              M4Q_QP_REF_LQR */
 
 /* plant_kind */
 #define M4Q_PLANT_NONE 0        /* caller supplies xs[step+1] between m4q_session_run calls */
@@ -192,6 +192,10 @@ M4Q_API int m4q_session_set_codes(m4q_session* s, const int32_t* codes);
 M4Q_API int m4q_session_kernel_ms(m4q_session* s, double* total_ms, int32_t* launches);
 /* 1 if the uploaded problem qualifies for (and will run on) the real-arithmetic path, else 0 */
 M4Q_API int m4q_session_path(const m4q_session* s);
+/* M4Q_QP_EXACT_BOX sessions: counters of the last launch - out[0] QP solves, out[1] Riccati sweeps with pinned
+ * controls, out[2] ratio-test steps, out[3..5] solves ended by the KKT test / at working precision / by the iteration
+ * cap (the last two leave a feasible, possibly sub-optimal point).  All zero for a clipped-Riccati session. */
+M4Q_API int m4q_session_qp_stats(m4q_session* s, int64_t* out6);
 /* resident bytes and launch geometry, for reports */
 M4Q_API int m4q_session_info(const m4q_session* s, int64_t* hbm_bytes, int32_t* grid, int32_t* lds_bytes);
 

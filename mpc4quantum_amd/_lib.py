@@ -72,6 +72,7 @@ PROTOTYPES = {
     "m4q_session_set_codes": (C.c_int, [_vp, _ip]),
     "m4q_session_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_double), _ip]),
     "m4q_session_info": (C.c_int, [_vp, C.POINTER(C.c_int64), _ip, _ip]),
+    "m4q_session_qp_stats": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     "m4q_session_path": (C.c_int, [_vp]),
 }
 

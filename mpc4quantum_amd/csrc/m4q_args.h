@@ -27,7 +27,8 @@ struct MpcArgs {
   cplx* Xg; double* Ug;                     // per-instance SQP guess  [B][T+1][n] complex, [B][T][m] (resumable state)
   // per resident row (grid*4 of them): working guess followed by the QP solution (S [2][rows][T+1][n], [2][rows][T][m]), gains (S)
   void* ws_Xg; double* ws_Ug; void* ws_gains;
-  int* queue;                               // next work item to hand out; zeroed before every launch
+  int* queue;                               // 64 B zeroed before every launch: [0] next work item to hand out;
+                                            // as u64 [1..3]: exact-QP counters (solves, Newton iterations, arc trials)
   int* head_done;                           // [B] set when an instance's head item (steps < 2) has been published; zeroed likewise
 };
 
@@ -81,7 +82,7 @@ struct ShapeOps {
   int (*launch_plant)(const PlantArgs&, hipStream_t);
   int (*launch_discretize)(const DiscArgs&, int real_path, hipStream_t);
   int (*power_list)(int32_t* out);
-  int (*occupancy)(int plant_kind, int real_path);   // resident workgroups per CU of the fused kernel
+  int (*occupancy)(int plant_kind, int real_path, int exact_qp);   // resident workgroups per CU of the fused kernel
 };
 
 }  // namespace m4q

@@ -222,6 +222,8 @@ int m4q_session_create(const m4q_problem* p, int32_t B, int32_t device, m4q_sess
   if (p->horizon < 1 || p->n_steps < 1 || p->target_cols < p->horizon + 1 + (p->n_steps > 1 ? p->n_steps - 2 : 0))
     return fail(M4Q_E_BADARG, "horizon/n_steps/target_cols inconsistent (need target_cols >= n_steps + horizon - 1)");
   if (!(p->sat > 0)) return fail(M4Q_E_BADARG, "sat must be positive (the reference crashes on sat=None, mpc.py Q5)");
+  if ((p->qp_flags & M4Q_QP_EXACT_BOX) && (p->qp_flags & M4Q_QP_REF_LQR))
+    return fail(M4Q_E_BADARG, "M4Q_QP_EXACT_BOX cannot be combined with M4Q_QP_REF_LQR");
   {
     // per-instance targets / plant operators are reached through 32-bit byte offsets from one base
     const double lim = 4294967296.0;
@@ -274,14 +276,16 @@ int m4q_session_create(const m4q_problem* p, int32_t B, int32_t device, m4q_sess
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, s->device));
   // the grid (and the per-row workspace) is sized for whichever path keeps more workgroups resident
-  int per_cu = std::max(sh->occupancy(p->plant_kind, 0), s->force_complex ? 0 : sh->occupancy(p->plant_kind, 1));
+  const int exact = (p->qp_flags & M4Q_QP_EXACT_BOX) ? 1 : 0;
+  int per_cu = std::max(sh->occupancy(p->plant_kind, 0, exact), s->force_complex ? 0 : sh->occupancy(p->plant_kind, 1, exact));
   if (per_cu < 1) per_cu = 1;
   const int nquads = (B + 3) / 4;
   long resident = (long)per_cu * prop.multiProcessorCount;
   s->grid = (int)(nquads < resident ? nquads : resident);
   const size_t rows = (size_t)s->grid * 4;
-  if (!rc) rc = s->wsXg.alloc(2 * rows * (T + 1) * n * C);      // [Xg rows][Xo rows]
-  if (!rc) rc = s->wsUg.alloc(2 * rows * T * m * 8);            // [Ug rows][Uo rows]
+  // [Xg rows][Xo rows] and [Ug rows][Uo rows]; the exact QP adds [Xalt rows] and [Ualt][working set][Newton point]
+  if (!rc) rc = s->wsXg.alloc((exact ? 3 : 2) * rows * (T + 1) * n * C);
+  if (!rc) rc = s->wsUg.alloc((exact ? 5 : 2) * rows * T * m * 8);
   if (!rc) rc = s->queue.alloc(64);
   if (!rc) rc = s->head_done.alloc((size_t)B * 4);
   if (!rc) rc = s->wsG.alloc(rows * T * (n + 1) * m * C);
@@ -542,6 +546,15 @@ int m4q_session_kernel_ms(m4q_session* s, double* total_ms, int32_t* launches) {
   return 0;
 }
 
+int m4q_session_qp_stats(m4q_session* s, int64_t* out6) {
+  if (!s || !out6) return fail(M4Q_E_BADARG, "m4q_session_qp_stats: bad argument");
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  unsigned long long q[8];
+  HIP_TRY(hipMemcpy(q, s->queue.p, sizeof(q), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 6; ++i) out6[i] = (int64_t)q[1 + i];
+  return 0;
+}
+
 int m4q_session_info(const m4q_session* s, int64_t* hbm_bytes, int32_t* grid, int32_t* lds_bytes) {
   if (!s) return fail(M4Q_E_BADARG, "m4q_session_info: null session");
   int64_t tot = 0;
@@ -657,8 +670,10 @@ int m4q_quad_program_batch(int32_t B, int32_t dim_x, int32_t dim_u, int32_t T, i
   a.X_opt = (cplx*)d_xo; a.U_opt = (double*)d_uo; a.cost = (double*)d_c; a.gains = (cplx*)d_g;
   if (qp_flags & M4Q_QP_EXACT_BOX) {
     void *d_xa, *d_ua, *d_st, *d_un;
-    if ((rc = t.up(nullptr, (size_t)B * (T + 1) * n * C, &d_xa))) return rc;
-    if ((rc = t.up(nullptr, (size_t)B * T * m * 8, &d_ua))) return rc;
+    if ((double)B * (T + 1) * n * C * 2 >= 4294967296.0)
+      return fail(M4Q_E_BADARG, "M4Q_QP_EXACT_BOX: batch too large for one call (trajectory workspace must stay below 4 GiB)");
+    if ((rc = t.up(nullptr, 2 * (size_t)B * (T + 1) * n * C, &d_xa))) return rc;
+    if ((rc = t.up(nullptr, 2 * (size_t)B * T * m * 8, &d_ua))) return rc;
     if ((rc = t.up(nullptr, (size_t)B * T * m * 8, &d_st))) return rc;
     if ((rc = t.up(nullptr, (size_t)B * T * m * 8, &d_un))) return rc;
     a.X_alt = (cplx*)d_xa; a.U_alt = (double*)d_ua; a.pin_stat = (double*)d_st; a.U_newton = (double*)d_un;

@@ -100,7 +100,7 @@ constexpr size_t mpc_lds_layout_bytes() {
 
 __device__ __forceinline__ int row_bcast_int(int v) { return __shfl(v, 0, 16); }
 
-template <class S, int PLANT>
+template <class S, int PLANT, bool EXACT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>::value, 8))) void mpc_kernel(MpcArgs a) {
   // LDS: [4 x scratch (complex)] [4 x model (S)] [Q Qf R (S)] [line-search weights]
   cplx* scratch = reinterpret_cast<cplx*>(m4q_lds_raw);
@@ -135,6 +135,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
   const GView Xo = gview(static_cast<S*>(a.ws_Xg), (long)blockIdx.x * ROWS * sX, g * sX + gridDim.x * ROWS * sX);
   const GView Uo = gview(a.ws_Ug, (long)blockIdx.x * ROWS * sU, g * sU + gridDim.x * ROWS * sU);
   const GView gains = gview(static_cast<S*>(a.ws_gains), (long)blockIdx.x * ROWS * sG, g * sG);
+  // EXACT (M4Q_QP_EXACT_BOX): third trajectory pair, working set and Newton point of the projected-Newton solver,
+  // again behind the others in the same allocations
+  const GView Xalt = gview(static_cast<S*>(a.ws_Xg), (long)blockIdx.x * ROWS * sX, g * sX + 2 * gridDim.x * ROWS * sX);
+  const GView Ualt = gview(a.ws_Ug, (long)blockIdx.x * ROWS * sU, g * sU + 2 * gridDim.x * ROWS * sU);
+  const GView pin_stat = gview(a.ws_Ug, (long)blockIdx.x * ROWS * sU, g * sU + 3 * gridDim.x * ROWS * sU);
   FusedProv<S, NX, NU, ORDER> prov;
   prov.mdl = mdl; prov.Xg = Xg; prov.Ug = Ug; prov.j = j;
   const long sXs = (long)(a.n_steps + 1) * NX, sUs = (long)a.n_steps * NU;
@@ -273,9 +278,51 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
 #pragma unroll
     for (int k = 0; k < NU; ++k) uapp[k] = 0.0;
     double chk = 0.0;
-    if constexpr (!(M4Q_EXP & 4))
-      chk = rollout_forward<S, NX, NU, false>(prov, T, x_cur, win, cost, a.flags, gains, a.sat, lo0, hi0, Xo, Uo, j, st, uapp,
-                                              !use_ls, &Xg, &Ug);
+    if constexpr (EXACT) {
+      // start from the current SQP guess (the shifted previous solution on warm steps: nearly the right working
+      // set), clipped into the box and rolled out through the linearised model; then projected Newton to the optimum
+      // of the box-constrained QP.  The linearisation point (Xg, Ug) must stay untouched until the solve is over.
+      Box box;
+      box.sat = a.sat;
+      chk = rollout_arc<S, NX, NU>(prov, T, x_cur, win, cost, Ug, Ug, 0.0, box, lo0, hi0, Xo, Uo, j, st);
+      wave_sync();
+      const bool go = running && finite_d(chk);
+      bool in_a = true;
+      QpStats stats;
+      chk = solve_box_qp<S, NX, NU>(prov, T, x_cur, win, cost, a.flags, gains, box, lo0, hi0, Xo, Uo, Xalt, Ualt, pin_stat, chk, go,
+                                    j, jj, lane_ok, in_a, stats);
+      if (running && jj == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 1, 1ull);
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 2, (unsigned long long)stats.newton);
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 3, (unsigned long long)stats.arcs);
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 4, (unsigned long long)stats.end_kkt);
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 5, (unsigned long long)stats.end_precision);
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 6, (unsigned long long)stats.end_cap);
+      }
+      GView Xs = Xo, Us = Uo;
+      Xs.off = in_a ? Xo.off : Xalt.off;
+      Us.off = in_a ? Uo.off : Ualt.off;
+      if (go) {
+#pragma unroll
+        for (int k = 0; k < NU; ++k) uapp[k] = Us.ld<double>(k);
+        if (use_ls) {
+          if (!in_a) {
+            if (lane_ok)
+              for (int t = 0; t <= T; ++t) Xo.st<S>(t * NX + j, Xs.ld<S>(t * NX + j));
+            for (int e = jj; e < T * NU; e += 16) Uo.st<double>(e, Us.ld<double>(e));
+          }
+        } else {
+          // warm step (alpha = 1, mpc.py:208-212): the solution becomes the next guess, shifted (mpc.py:271-272)
+          if (lane_ok)
+            for (int t = 0; t <= T; ++t) Xg.st<S>(t * NX + j, Xs.ld<S>((t < T ? t + 1 : T) * NX + j));
+          for (int e = jj; e < T * NU; e += 16) Ug.st<double>(e, Us.ld<double>(e + NU < T * NU ? e + NU : e));
+        }
+      }
+    } else {
+      if constexpr (!(M4Q_EXP & 4))
+        chk = rollout_forward<S, NX, NU, false>(prov, T, x_cur, win, cost, a.flags, gains, a.sat, lo0, hi0, Xo, Uo, j, st, uapp,
+                                                !use_ls, &Xg, &Ug);
+    }
     wave_sync();
     const bool fail = !finite_d(chk);                      // mpc.py:200-203
     if (running) ++iter;
@@ -522,22 +569,34 @@ __global__ __launch_bounds__(64) M4Q_OCC void qp_kernel(QpArgs a) {
     wave_sync();
     double obj_out = obj;
     if (a.flags & QP_EXACT_BOX) {
-      const GView Xb = gview(a.X_alt, q0 * sX, gl * sX);
-      const GView Ub = gview(a.U_alt, q0 * sU, gl * sU);
+      // the solver ping-pongs between two trajectory pairs of ONE allocation (rows pick theirs by lane offset):
+      // X_alt = [B][T+1][n] twice, U_alt likewise
+      const GView Xa = gview(a.X_alt, q0 * sX, gl * sX);
+      const GView Ua = gview(a.U_alt, q0 * sU, gl * sU);
+      const GView Xb = gview(a.X_alt, q0 * sX, gl * sX + (unsigned)a.B * sX);
+      const GView Ub = gview(a.U_alt, q0 * sU, gl * sU + (unsigned)a.B * sU);
       const GView stat = gview(a.pin_stat, q0 * sU, gl * sU);
-      const GView Un = gview(a.U_newton, q0 * sU, gl * sU);
+      if (st) {
+        for (int t = 0; t <= T; ++t) Xa.st<cplx>(t * NX + j, Xo.ld<cplx>(t * NX + j));
+        if (j == 0)
+          for (int i = 0; i < T * NU; ++i) Ua.st<double>(i, Uo.ld<double>(i));
+      }
+      wave_sync();
       Box box;
       box.sat = a.sat;
       bool in_a;
-      int n_newton;
-      obj_out = solve_box_qp<cplx, NX, NU>(prov, T, x0, win, cost, a.flags, gains, box, lo0, hi0, Xo, Uo, Xb, Ub, stat, Un, obj,
-                                           valid, j, L.lane_ok, in_a, n_newton);
-      if (!in_a && st) {                                  // the answer sits in the alternate pair
-        for (int t = 0; t <= T; ++t) Xo.st<cplx>(t * NX + j, Xb.ld<cplx>(t * NX + j));
+      QpStats stats;
+      obj_out = solve_box_qp<cplx, NX, NU>(prov, T, x0, win, cost, a.flags, gains, box, lo0, hi0, Xa, Ua, Xb, Ub, stat, obj, valid,
+                                           j, jj, L.lane_ok, in_a, stats);
+      GView Xs = Xa, Us = Ua;
+      Xs.off = in_a ? Xa.off : Xb.off;
+      Us.off = in_a ? Ua.off : Ub.off;
+      if (st) {
+        for (int t = 0; t <= T; ++t) Xo.st<cplx>(t * NX + j, Xs.ld<cplx>(t * NX + j));
         if (j == 0)
-          for (int i = 0; i < T * NU; ++i) Uo.st<double>(i, Ub.ld<double>(i));
+          for (int i = 0; i < T * NU; ++i) Uo.st<double>(i, Us.ld<double>(i));
       }
-      if (valid && jj == 0 && a.newton_iters) a.newton_iters[b] = n_newton;
+      if (valid && jj == 0 && a.newton_iters) a.newton_iters[b] = stats.newton;
       wave_sync();
     }
     if (valid && jj == 0) a.cost[b] = obj_out;
@@ -671,51 +730,57 @@ static int prep_lds(K kern, size_t bytes) {
   return 0;
 }
 
-template <class S, int PLANT>
-static int launch_mpc_t(const MpcArgs& a, int grid, hipStream_t s) {
-  const size_t lds = mpc_lds_layout_bytes<S>();
-  int rc = prep_lds(mpc_kernel<S, PLANT>, lds);
-  if (rc) return rc;
-  hipLaunchKernelGGL((mpc_kernel<S, PLANT>), dim3(grid), dim3(64), lds, s, a);
-  return -(int)hipGetLastError();
+// what to do with the kernel instance picked by (arithmetic path, plant kind, QP mode)
+struct LaunchOp {
+  const MpcArgs& a;
+  int grid;
+  hipStream_t s;
+  template <class S, int PLANT, bool EXACT>
+  int run() const {
+    const size_t lds = mpc_lds_layout_bytes<S>();
+    int rc = prep_lds(mpc_kernel<S, PLANT, EXACT>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((mpc_kernel<S, PLANT, EXACT>), dim3(grid), dim3(64), lds, s, a);
+    return -(int)hipGetLastError();
+  }
+};
+struct OccupancyOp {
+  template <class S, int PLANT, bool EXACT>
+  int run() const {
+    int nb = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mpc_kernel<S, PLANT, EXACT>, 64, mpc_lds_layout_bytes<S>());
+    return e != hipSuccess ? -(int)e : nb;
+  }
+};
+
+template <class S, bool EXACT, class Op>
+static int pick_plant(const Op& op, int plant_kind) {
+  if constexpr (!SQUARE) {
+    return op.template run<S, PLANT_NONE, EXACT>();
+  } else {
+    if (plant_kind == PLANT_HAMILTONIAN) return op.template run<S, PLANT_HAMILTONIAN, EXACT>();
+    if (plant_kind == PLANT_GENERATOR) return op.template run<S, PLANT_GENERATOR, EXACT>();
+    return op.template run<S, PLANT_NONE, EXACT>();
+  }
+}
+
+template <class Op>
+static int pick_kernel(const Op& op, int plant_kind, int real_path, int exact, int unsupported) {
+  if constexpr (!SQUARE) {
+    if (real_path || plant_kind != PLANT_NONE) return unsupported;
+  }
+  if (real_path) {
+    if constexpr (SQUARE) return exact ? pick_plant<double, true>(op, plant_kind) : pick_plant<double, false>(op, plant_kind);
+  }
+  return exact ? pick_plant<cplx, true>(op, plant_kind) : pick_plant<cplx, false>(op, plant_kind);
 }
 
 static int launch_mpc(const MpcArgs& a, int plant_kind, int real_path, int grid, hipStream_t s) {
-  if constexpr (!SQUARE) {
-    if (real_path || plant_kind != PLANT_NONE) return -(int)hipErrorInvalidValue;
-    return launch_mpc_t<cplx, PLANT_NONE>(a, grid, s);
-  } else {
-  if (real_path) {
-    if (plant_kind == PLANT_HAMILTONIAN) return launch_mpc_t<double, PLANT_HAMILTONIAN>(a, grid, s);
-    if (plant_kind == PLANT_GENERATOR) return launch_mpc_t<double, PLANT_GENERATOR>(a, grid, s);
-    return launch_mpc_t<double, PLANT_NONE>(a, grid, s);
-  }
-  if (plant_kind == PLANT_HAMILTONIAN) return launch_mpc_t<cplx, PLANT_HAMILTONIAN>(a, grid, s);
-  if (plant_kind == PLANT_GENERATOR) return launch_mpc_t<cplx, PLANT_GENERATOR>(a, grid, s);
-  return launch_mpc_t<cplx, PLANT_NONE>(a, grid, s);
-  }
+  return pick_kernel(LaunchOp{a, grid, s}, plant_kind, real_path, (a.flags & QP_EXACT_BOX) != 0, -(int)hipErrorInvalidValue);
 }
 
-template <class S, int PLANT>
-static int occupancy_t() {
-  int nb = 0;
-  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mpc_kernel<S, PLANT>, 64, mpc_lds_layout_bytes<S>());
-  return e != hipSuccess ? -(int)e : nb;
-}
-
-static int occupancy(int plant_kind, int real_path) {
-  if constexpr (!SQUARE) {
-    return (real_path || plant_kind != PLANT_NONE) ? 0 : occupancy_t<cplx, PLANT_NONE>();
-  } else {
-  if (real_path) {
-    if (plant_kind == PLANT_HAMILTONIAN) return occupancy_t<double, PLANT_HAMILTONIAN>();
-    if (plant_kind == PLANT_GENERATOR) return occupancy_t<double, PLANT_GENERATOR>();
-    return occupancy_t<double, PLANT_NONE>();
-  }
-  if (plant_kind == PLANT_HAMILTONIAN) return occupancy_t<cplx, PLANT_HAMILTONIAN>();
-  if (plant_kind == PLANT_GENERATOR) return occupancy_t<cplx, PLANT_GENERATOR>();
-  return occupancy_t<cplx, PLANT_NONE>();
-  }
+static int occupancy(int plant_kind, int real_path, int exact) {
+  return pick_kernel(OccupancyOp{}, plant_kind, real_path, exact, 0);
 }
 
 static int grid_for(int B) {

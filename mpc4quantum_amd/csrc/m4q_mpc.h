@@ -314,16 +314,36 @@ __device__ __forceinline__ S qrow_times(const S* Qt, S v, int j) {
 // keeps loop-invariant LDS/global loads inside the horizon loops (hoisted, they cost hundreds of VGPRs)
 #define M4Q_NO_HOIST() asm volatile("" ::: "memory")
 
-// Working set of the exact box-QP solver (projected Newton, see solve_box_qp): stat [T][NU] doubles
-// (0 free, +-1 pinned at the upper/lower bound), Uk [T][NU] the current feasible iterate.
+struct Box {       // |u| <= sat, first control also within [lo0, hi0]
+  double sat;
+  template <int NU>
+  __device__ __forceinline__ void at(int t, int k, const double (&lo0)[NU], const double (&hi0)[NU], double& lo, double& hi) const {
+    lo = -sat;
+    hi = sat;
+    if (t == 0) { lo = fmax(lo, lo0[k]); hi = fmin(hi, hi0[k]); }
+  }
+};
+
+// Working set of the exact box-QP solver (see solve_box_qp): stat [T][NU] doubles, 0 free, +1 / -1 pinned at the
+// upper / lower bound.
+template <int NU>
 struct PinCtx {
   GView stat;
-  GView Uk;
+  Box box;
+  double lo0[NU], hi0[NU];
+  // pinned value of control k at horizon index t, or free
+  __device__ __forceinline__ bool pinned(int t, int k, double& value) const {
+    const double st = stat.ld<double>(t * NU + k);
+    double lo, hi;
+    box.at<NU>(t, k, lo0, hi0, lo, hi);
+    value = st > 0.0 ? hi : lo;
+    return st != 0.0;
+  }
 };
 
 template <class S, int NX, int NU, class Prov, bool PINNED = false>
 __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const Window& win, const CostRef<S>& cost, int flags,
-                                                  const GView& gains, int j, bool store_ok, const PinCtx* pin = nullptr) {
+                                                  const GView& gains, int j, bool store_ok, const PinCtx<NU>* pin = nullptr) {
   const bool ref = (flags & QP_REF_LQR) != 0;
   S Pc[NX];
   S pv = zero_of<S>();
@@ -397,8 +417,9 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
       //   G_ff du_f = -(H_f dx + h_f + G_fp du_p)
 #pragma unroll
       for (int k = 0; k < NU; ++k) {
-        fix[k] = pin->stat.template ld<double>(t * NU + k) != 0.0;
-        dufix[k] = fix[k] ? pin->Uk.template ld<double>(t * NU + k) - ub[k] : 0.0;
+        double v;
+        fix[k] = pin->pinned(t, k, v);
+        dufix[k] = fix[k] ? v - ub[k] : 0.0;
       }
 #pragma unroll
       for (int k = 0; k < NU; ++k) {
@@ -613,33 +634,36 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
 
 // ---------------------------------------------------------------------------------------------
 // Exact box-constrained QP (the statement of optimize.quad_program, optimize.py:27-43,54, which the live reference
-// hands to OSQP): projected Newton (Bertsekas 1982) on the Riccati factorisation.
-//   iterate  u^k feasible (start: the clipped Riccati rollout);
-//   1. adjoint sweep -> gradient g = dJ/du at u^k; a control sitting on a bound with the gradient pushing outward
-//      is pinned, everything else is free;
-//   2. Riccati sweep with the pinned controls held (riccati_backward<PINNED>) = Newton step for the free ones;
-//   3. closed-loop unclipped rollout -> Newton point u_N; projection arc u(a) = clip(u^k + a (u_N - u^k)), a = 1, 1/2, ...
-//      accepted at the first decrease of the objective (open-loop rollouts).
-// Terminates when the Newton point is the iterate (then the KKT conditions hold) or nothing decreases.
+// hands to OSQP): a primal active-set method on the Riccati factorisation.
+//   iterate  u^k feasible, x^k its (linearised-model) trajectory, J^k its objective, W the working set (controls
+//   pinned on a bound);
+//   1. Riccati sweep with the controls of W held (riccati_backward<PINNED>): policy of the minimiser of J over the face;
+//   2. closed-loop rollout of that policy, clipping the free controls that leave the box (the feedback re-plans the
+//      later ones around each clipped value).  Nothing clipped: it is the face minimiser u_N.  Either way the point is
+//      feasible and becomes the next iterate if J decreases (large changes of the active set in one step);
+//   3. otherwise the classical step: unclipped rollout -> u_N, move along the segment u^k -> u_N up to the first bound
+//      met (ratio test), pin the control(s) met there - all of them: with a step of length zero (free controls sitting
+//      on a bound the Newton step wants to cross, common with these stiff Hessians) they would otherwise come one per
+//      sweep.  J(a) = J_N + (J^k - J_N)(1 - a)^2 along the segment, so this always decreases J and needs no
+//      evaluation; trajectories blend linearly;
+//   4. W is re-derived from the gradient (adjoint sweep: a control on a bound with the gradient pushing outward is
+//      pinned, all others free) after 2; kept, plus the blocking control, after 3.
+// Converged when a face minimiser is followed by an unchanged working set (multipliers of the right sign = KKT).
+// J decreases strictly from iterate to iterate, so no face is visited twice.
 // ---------------------------------------------------------------------------------------------
-struct Box {       // |u| <= sat, first control also within [lo0, hi0]
-  double sat;
-  template <int NU>
-  __device__ __forceinline__ void at(int t, int k, const double (&lo0)[NU], const double (&hi0)[NU], double& lo, double& hi) const {
-    lo = -sat;
-    hi = sat;
-    if (t == 0) { lo = fmax(lo, lo0[k]); hi = fmin(hi, hi0[k]); }
-  }
+struct QpStats {   // per row, counted by the caller
+  int newton = 0, arcs = 0;
+  int end_kkt = 0, end_precision = 0, end_cap = 0;   // how the solve ended
 };
 
-// gradient of the objective at (Xk, Uk) and the working set.  Returns the number of pinned controls (replicated).
+// gradient of the objective at (Xk, Uk) and the working set.  Returns the number of entries of the working set that
+// changed with respect to what `stat` held (replicated over the row).
 template <class S, int NX, int NU, class Prov>
 __device__ __forceinline__ int adjoint_working_set(const Prov& prov, int T, const Window& win, const CostRef<S>& cost, const GView& Xk,
-                                                    const GView& Uk, const Box& box, const double (&lo0)[NU],
-                                                    const double (&hi0)[NU], const GView& stat, int j, bool store_ok) {
+                                                    const GView& Uk, const PinCtx<NU>& pin, int j, bool store_ok) {
   // lam = Q_T e_T ;  g_t = 2 (R (u_t - ub_t) + Re B_t^H lam_{t+1}) ;  lam_t = Q_t e_t + A_t^H lam_{t+1}
   S lam = qrow_times<NX>(cost.q(T, T), csub(Xk.ld<S>(T * NX + j), win.xbm.ld<S>(T * NX + j)), j);
-  int npin = 0;
+  int nchg = 0;
   for (int t = T - 1; t >= 0; --t) {
     M4Q_NO_HOIST();
     const typename Prov::Lin lin = prov.fetch(t);
@@ -657,50 +681,88 @@ __device__ __forceinline__ int adjoint_working_set(const Prov& prov, int T, cons
 #pragma unroll
       for (int l = 0; l < NU; ++l) gk = fma(real_of(Rt[k * NU + l]), u[l] - ub[l], gk);
       double lo, hi;
-      box.at<NU>(t, k, lo0, hi0, lo, hi);
-      const double eps = 1e-12 * box.sat;
+      pin.box.template at<NU>(t, k, pin.lo0, pin.hi0, lo, hi);
+      const double eps = 1e-12 * pin.box.sat;
       double st = 0.0;
       if (u[k] <= lo + eps && gk > 0.0) st = -1.0;
       if (u[k] >= hi - eps && gk < 0.0) st = 1.0;
       if (hi - lo <= 2 * eps) st = 1.0;                  // degenerate interval: nothing to optimise
-      npin += st != 0.0 ? 1 : 0;
-      if (store_ok && j == 0) stat.st<double>(t * NU + k, st);
+      nchg += pin.stat.template ld<double>(t * NU + k) != st ? 1 : 0;
+      if (store_ok && j == 0) pin.stat.template st<double>(t * NU + k, st);
     }
     const S e = csub(Xk.ld<S>(t * NX + j), win.xbm.ld<S>(t * NX + j));
     lam = dot_lane_index<false, true, NX>(lam, Ac, qrow_times<NX>(cost.q(t, T), e, j));     // Q_t e_t + A_t^H lam
   }
-  return npin;
+  return nchg;
 }
 
-// closed-loop rollout of the Newton policy WITHOUT clipping (pinned controls keep their value): writes u_N,
-// returns max |u_N - u^k| (replicated).
+// What a policy rollout reports besides the objective (all replicated over the row).
+struct RolloutInfo {
+  double dmax;       // max |u - u^k|
+  bool outside;      // some free control left the box (before clipping)
+  double alpha;      // ratio test: largest step along u^k -> u that stays in the box (<= 1)
+};
+
+// closed-loop rollout of the policy in `gains` (pinned controls sit on their bound), with (clip) or without clipping
+// of the free controls.  Writes the trial point (Xc, Uc); returns the objective.
 template <class S, int NX, int NU, class Prov>
-__device__ __forceinline__ double rollout_newton(const Prov& prov, int T, S x0, const Window& win, int flags, const GView& gains,
-                                                 const PinCtx& pin, const GView& Un, int j, bool store_ok) {
+__device__ __forceinline__ double rollout_policy(const Prov& prov, int T, S x0, const Window& win, const CostRef<S>& cost,
+                                                 const GView& gains, const PinCtx<NU>& pin, const GView& Uk, bool clip,
+                                                 const GView& Xc, const GView& Uc, int j, bool store_ok, RolloutInfo& info) {
   S x = x0;
-  double dmax = 0.0;
+  if (store_ok) Xc.st<S>(j, x);
+  info.dmax = 0.0;
+  info.outside = false;
+  info.alpha = 1.0;
+  double cx = 0.0, cu = 0.0;
   for (int t = 0; t < T; ++t) {
     M4Q_NO_HOIST();
     const typename Prov::Lin lin = prov.fetch(t);
     S ax, Brow[NU], dlt;
     prov.rows(lin, x, ax, Brow, dlt);
     const S dx = csub(x, win.xbm.ld<S>(t * NX + j));
+    cx += dot_re(dx, qrow_times<NX>(cost.q(t, T), dx, j));
+    const S* Rt = cost.r(t);
     const unsigned gt = (unsigned)t * (NX + 1) * NU;
     S xn = cadd(ax, dlt);
+    double un[NU], eu[NU];
 #pragma unroll
     for (int k = 0; k < NU; ++k) {
-      const double uk = pin.Uk.ld<double>(t * NU + k);
-      const bool fixd = pin.stat.ld<double>(t * NU + k) != 0.0;
+      double pv;
+      const bool fixd = pin.pinned(t, k, pv);
+      const double ub = win.ubm.ld<double>(t * NU + k);
+      const double uk = Uk.ld<double>(t * NU + k);
       const double part = real_of(cmul(gains.ld<S>(gt + j * NU + k), dx));
-      double un = rowsum<NX>(part) + real_of(gains.ld<S>(gt + NX * NU + k)) + win.ubm.ld<double>(t * NU + k);
-      un = fixd ? uk : un;
-      dmax = fmax(dmax, fabs(un - uk));
-      if (store_ok && j == 0) Un.st<double>(t * NU + k, un);
-      cmac_r(xn, Brow[k], un);
+      const double v = rowsum<NX>(part) + real_of(gains.ld<S>(gt + NX * NU + k)) + ub;
+      un[k] = fixd ? pv : v;
+      double lo, hi;
+      pin.box.template at<NU>(t, k, pin.lo0, pin.hi0, lo, hi);
+      const bool above = un[k] > hi, below = un[k] < lo;
+      if (above || below) {
+        info.outside = true;
+        info.alpha = fmin(info.alpha, ((above ? hi : lo) - uk) / (un[k] - uk));        // u^k is feasible: 0 <= a < 1
+      }
+      if (clip) un[k] = fmin(fmax(un[k], lo), hi);
+      eu[k] = un[k] - ub;
+      info.dmax = fmax(info.dmax, fabs(un[k] - uk));
+      cmac_r(xn, Brow[k], un[k]);
     }
+#pragma unroll
+    for (int k = 0; k < NU; ++k)
+#pragma unroll
+      for (int l = 0; l < NU; ++l) cu = fma(eu[k] * real_of(Rt[k * NU + l]), eu[l], cu);
     x = xn;
+    if (store_ok) {
+      Xc.st<S>((t + 1) * NX + j, x);
+      if (j == 0) {
+#pragma unroll
+        for (int k = 0; k < NU; ++k) Uc.st<double>(t * NU + k, un[k]);
+      }
+    }
   }
-  return dmax;
+  const S e = csub(x, win.xbm.ld<S>(T * NX + j));
+  cx += dot_re(e, qrow_times<NX>(cost.q(T, T), e, j));
+  return rowsum<NX>(cx) + cu;
 }
 
 // open-loop rollout of u = clip(u^k + alpha (u_N - u^k)) with the objective of optimize.py:33-34,54; writes (Xc, Uc).
@@ -749,48 +811,107 @@ __device__ __forceinline__ double rollout_arc(const Prov& prov, int T, S x0, con
   return rowsum<NX>(cx) + cu;
 }
 
-// The exact solve for the four rows of a wavefront.  On entry (Xa, Ua) hold the clipped Riccati rollout and Ja its
-// objective; the two buffer pairs (Xa, Ua) / (Xb, Ub) ping-pong, `cur_is_a` tells which one holds the answer on exit.
-// `act` marks the rows that take part.  Returns the objective of the answer.
+// The exact solve for the four rows of a wavefront.  On entry (Xa, Ua) hold a feasible point with its linearised
+// trajectory and Ja its objective; the two buffer pairs (Xa, Ua) / (Xb, Ub) - which must share their wave-uniform
+// bases - ping-pong, `cur_is_a` tells which one holds the answer on exit.  `act` marks the rows that take part.
+// Returns the objective of the answer.
 template <class S, int NX, int NU, class Prov>
 __device__ __forceinline__ double solve_box_qp(const Prov& prov, int T, S x0, const Window& win, const CostRef<S>& cost, int flags,
                                                const GView& gains, const Box& box, const double (&lo0)[NU],
                                                const double (&hi0)[NU], GView Xa, GView Ua, GView Xb, GView Ub, const GView& stat,
-                                               const GView& Un, double Ja, bool act, int j, bool lane_ok, bool& cur_is_a,
-                                               int& n_newton) {
+                                               double Ja, bool act, int j, int jj, bool lane_ok, bool& cur_is_a, QpStats& stats) {
   bool going = act;
+  bool need_adj = true;          // the working set has to be (re-)derived from the gradient at the iterate
+  bool face_min = false;         // the iterate minimises J over the face of the working set in `stat`
+  int stalls = 0;
   double Jk = Ja;
   cur_is_a = true;
-  n_newton = 0;
-  for (int it = 0; it < 50 && __any(going); ++it) {
-    const GView Xk = cur_is_a ? Xa : Xb, Uk = cur_is_a ? Ua : Ub;
-    const GView Xc = cur_is_a ? Xb : Xa, Uc = cur_is_a ? Ub : Ua;
-    const bool st = going && lane_ok;
-    adjoint_working_set<S, NX, NU>(prov, T, win, cost, Xk, Uk, box, lo0, hi0, stat, j, st);
-    wave_sync();
-    PinCtx pin;
-    pin.stat = stat;
-    pin.Uk = Uk;
-    riccati_backward<S, NX, NU, Prov, true>(prov, T, win, cost, flags, gains, j, st, &pin);
-    wave_sync();
-    const double dmax = rollout_newton<S, NX, NU>(prov, T, x0, win, flags, gains, pin, Un, j, st);
-    wave_sync();
-    if (going) ++n_newton;
-    if (!(dmax > 1e-13 * box.sat)) going = false;            // Newton point == iterate (or NaN): KKT point reached
-    // projection arc with backtracking
-    double alpha = 1.0;
-    bool searching = going;
-    bool accepted = false;
-    for (int ls = 0; ls < 30 && __any(searching); ++ls) {
-      const double Jc = rollout_arc<S, NX, NU>(prov, T, x0, win, cost, Uk, Un, alpha, box, lo0, hi0, Xc, Uc, j, searching && lane_ok);
+  PinCtx<NU> pin;
+  pin.stat = stat;
+  pin.box = box;
+#pragma unroll
+  for (int k = 0; k < NU; ++k) { pin.lo0[k] = lo0[k]; pin.hi0[k] = hi0[k]; }
+  for (int it = 0; it < 100 && __any(going); ++it) {
+    // per-row source / destination: same wave-uniform bases, lane offsets swapped
+    GView Xk = Xa, Uk = Ua, Xc = Xb, Uc = Ub;
+    Xk.off = cur_is_a ? Xa.off : Xb.off;
+    Uk.off = cur_is_a ? Ua.off : Ub.off;
+    Xc.off = cur_is_a ? Xb.off : Xa.off;
+    Uc.off = cur_is_a ? Ub.off : Ua.off;
+    if (__any(going && need_adj)) {
+      const bool adj = going && need_adj;
+      const int nchg = adjoint_working_set<S, NX, NU>(prov, T, win, cost, Xk, Uk, pin, j, adj && lane_ok);
       wave_sync();
-      if (searching && Jc < Jk) { accepted = true; searching = false; Jk = Jc; }
-      alpha *= 0.5;
+      if (adj && face_min && nchg == 0) { going = false; ++stats.end_kkt; }   // face minimiser, multipliers of the right sign
+      if (!__any(going)) break;
     }
-    if (going && !accepted) going = false;                    // no decrease along the arc: the iterate stands
-    if (going) cur_is_a = !cur_is_a;
+    need_adj = false;
+    face_min = false;
+    riccati_backward<S, NX, NU, Prov, true>(prov, T, win, cost, flags, gains, j, going && lane_ok, &pin);
+    wave_sync();
+    RolloutInfo ri;
+    const double Jc = rollout_policy<S, NX, NU>(prov, T, x0, win, cost, gains, pin, Uk, true, Xc, Uc, j, going && lane_ok, ri);
+    wave_sync();
+    if (going) ++stats.newton;
+    bool moved = false;
+    if (going && !(ri.dmax > 1e-13 * box.sat)) {
+      // the policy reproduces the iterate: it is the minimiser of its face (or NaN)
+      if (!(ri.dmax == ri.dmax) || ++stalls > 1) { going = false; ++stats.end_precision; }
+      face_min = true;
+      need_adj = true;
+    } else if (going && (Jc < Jk || (!ri.outside && Jc <= Jk + 1e-12 * fabs(Jk) && stalls < 2))) {
+      // (a face minimiser is taken even without a visible decrease: near the optimum J is flat to working precision
+      //  long before the controls are, and the Newton point is the more accurate of the two)
+      stalls = Jc < Jk ? 0 : stalls + 1;
+      moved = true;
+      Jk = Jc;
+      face_min = !ri.outside;
+      need_adj = true;
+    } else if (going && !ri.outside) {
+      going = false;                                           // face minimiser without decrease: working precision
+      ++stats.end_precision;
+    }
+    // classical step for the rows whose clipped rollout did not decrease J
+    const bool ratio = going && !moved && !face_min;
+    if (__any(ratio)) {
+      RolloutInfo rn;
+      const double Jn = rollout_policy<S, NX, NU>(prov, T, x0, win, cost, gains, pin, Uk, false, Xc, Uc, j, ratio && lane_ok, rn);
+      wave_sync();
+      if (ratio) {
+        ++stats.arcs;
+        const double al = rn.alpha;
+        // blend in place: trial = iterate + al (Newton - iterate); the blocking control lands exactly on its bound
+        if (lane_ok) {
+#pragma unroll 4
+          for (int t = 0; t <= T; ++t) {
+            const S xk = Xk.ld<S>(t * NX + j), xn = Xc.ld<S>(t * NX + j);
+            Xc.st<S>(t * NX + j, cadd(xk, cscale(csub(xn, xk), al)));
+          }
+        }
+        for (int e = jj; e < T * NU; e += 16) {
+          const double uk = Uk.ld<double>(e), un = Uc.ld<double>(e);
+          double v = fma(al, un - uk, uk);
+          double lo, hi;
+          box.at<NU>(e / NU, e % NU, lo0, hi0, lo, hi);
+          const bool above = un > hi, below = un < lo;
+          if ((above || below) && ((above ? hi : lo) - uk) / (un - uk) <= al + 1e-14) {
+            v = above ? hi : lo;                               // blocking: lands exactly on its bound and is pinned
+            stat.st<double>(e, above ? 1.0 : -1.0);
+          }
+          Uc.st<double>(e, v);
+        }
+        const double r = 1.0 - al;
+        Jk = fma(Jk - Jn, r * r, Jn);                          // J along the segment to the face minimiser
+        moved = true;
+        // al == 0 (degenerate): a free control sits on the bound the step wants to cross; it is pinned now, nothing moved
+        stalls = al > 0.0 ? 0 : stalls + 1;
+        if (stalls > 2 * NU * T) { going = false; ++stats.end_cap; }
+      }
+    }
+    if (going && moved) cur_is_a = !cur_is_a;
     wave_sync();
   }
+  if (going) ++stats.end_cap;
   return Jk;
 }
 

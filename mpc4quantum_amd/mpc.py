@@ -100,8 +100,10 @@ def _trim(xs, us, code, done):
 
 
 def mpc(x0, dim_u, order, X_targ, U_targ, clock, experiment, model, Q, R, Qf, sat=None, du=None, max_iter=100,
-        exit_condition=None, streaming=False, warm_start=True, progress_bar=True, verbose=False):
-    """Drop-in for mpc4quantum.mpc.mpc (mpc.py:128-304): returns ([xs, us], model, exit_code)."""
+        exit_condition=None, streaming=False, warm_start=True, progress_bar=True, verbose=False, exact_qp=False):
+    """Drop-in for mpc4quantum.mpc.mpc (mpc.py:128-304): returns ([xs, us], model, exit_code).
+    exact_qp (extension): solve each QP to the box-constrained optimum, as the reference's OSQP call does, instead of
+    clipping the Riccati rollout (identical whenever no bound is active)."""
     mf = int(clock.measure_freq)
     x0 = np.asarray(x0, dtype=np.complex128).reshape(-1)
     lift_x0 = np.asarray(experiment.lift(x0), dtype=np.complex128).reshape(-1)
@@ -115,7 +117,7 @@ def mpc(x0, dim_u, order, X_targ, U_targ, clock, experiment, model, Q, R, Qf, sa
     fused = _native_plant(experiment) and exit_condition is None and not streaming
     kind = experiment.plant_kind if fused else _lib.PLANT_NONE
     sess = EnsembleSession(1, n, dim_u, order, T, ns, clock.dt, sat, du, max_iter, warm_start, plant_kind=kind,
-                           target_cols=cols, measure_freq=mf)
+                           target_cols=cols, measure_freq=mf, exact_qp=exact_qp)
     try:
         op0, ops = experiment.operators() if fused else (None, None)
         sess.load_problem(np.hstack([A_x, A_u])[None], lift_x0[None], X_targ, U_targ, Q, R, Qf, op0, ops)
@@ -189,7 +191,7 @@ class _HeldControl:
 
 def mpc_batch(x0, models, dim_u, order, X_targ, U_targ, clock, plant_op0, plant_ops, Q, R, Qf, sat, du=None,
               max_iter=100, warm_start=True, qp_flags=None, plant_kind=_lib.PLANT_HAMILTONIAN, device=-1, session=None,
-              force_complex=False):
+              force_complex=False, exact_qp=False):
     """B independent closed loops in one launch.
     x0 [B, n]; models [B|1, n, n(1+P)]; X_targ (n, cols) / U_targ (m, cols) shared (or [B, ...] each);
     plant_op0 [B|1, k, k], plant_ops [B|1, m, k, k].  Returns a dict: xs [B, n, n_steps+1], us [B, m, n_steps]
@@ -216,12 +218,15 @@ def mpc_batch(x0, models, dim_u, order, X_targ, U_targ, clock, plant_op0, plant_
     own = session is None
     sess = session or EnsembleSession(Bn, n, dim_u, order, T, ns, clock.dt, sat, du, max_iter, warm_start, qp_flags,
                                       plant_kind, models.shape[0] > 1, per_plant, per_targ, cols, device=device,
-                                      force_complex=force_complex, measure_freq=getattr(clock, "measure_freq", 1))
+                                      force_complex=force_complex, measure_freq=getattr(clock, "measure_freq", 1),
+                                      exact_qp=exact_qp)
     try:
         sess.load_problem(models, x0, X_targ, U_targ, Q, R, Qf, op0, ops)
         sess.run(0, ns)
         res = sess.results()
         res["path"] = sess.path()
+        res["kernel_ms"] = sess.kernel_ms()[0]
+        res["qp_stats"] = sess.qp_stats()
     finally:
         if own:
             sess.close()

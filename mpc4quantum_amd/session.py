@@ -17,13 +17,18 @@ _DTYPES = {
 class EnsembleSession:
     def __init__(self, B, dim_x, dim_u, order, horizon, n_steps, dt, sat, du=None, max_iter=100, warm_start=True,
                  qp_flags=None, plant_kind=_lib.PLANT_HAMILTONIAN, model_per_instance=False, plant_per_instance=False,
-                 target_per_instance=False, target_cols=None, ls_tol=1e-4, device=-1, force_complex=False, measure_freq=1):
+                 target_per_instance=False, target_cols=None, ls_tol=1e-4, device=-1, force_complex=False, measure_freq=1,
+                 exact_qp=False):
+        """exact_qp: solve every QP of the loop to the box-constrained optimum (M4Q_QP_EXACT_BOX, what the reference's OSQP
+        call converges to) instead of clipping the Riccati rollout."""
         if sat is None:
             raise TypeError("sat is required (the reference negates it unconditionally, optimize.py:43 / lqr.py:76)")
         p = _lib.Problem()
         p.dim_x, p.dim_u, p.order, p.horizon, p.n_steps = dim_x, dim_u, order, horizon, n_steps
         p.max_iter, p.warm_start = int(max_iter), int(bool(warm_start))
         p.qp_flags = int(qp_flags if qp_flags is not None else (_lib.QP_DU_BAND if du is not None else 0))
+        if exact_qp:
+            p.qp_flags |= _lib.QP_EXACT_BOX
         p.plant_kind = int(plant_kind)
         p.model_per_instance, p.plant_per_instance = int(model_per_instance), int(plant_per_instance)
         p.target_per_instance = int(target_per_instance)
@@ -98,6 +103,13 @@ class EnsembleSession:
         n = C.c_int32()
         _lib.check(self._L.m4q_session_kernel_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def qp_stats(self):
+        """exact_qp sessions: (QP solves, pinned Riccati sweeps, ratio-test steps, solves ended by KKT / at working
+        precision / by the iteration cap) of the last launch."""
+        out = (C.c_int64 * 6)()
+        _lib.check(self._L.m4q_session_qp_stats(self._h, out))
+        return tuple(int(v) for v in out)
 
     def path(self):
         """'real' if the uploaded problem runs in the Hermitian operator basis with real arithmetic, else 'complex'."""

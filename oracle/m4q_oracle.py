@@ -577,9 +577,9 @@ class OracleQCoupledExperiment(OracleQExperiment):
 def mpc(x0, dim_u, order, X_targ, U_targ, clock, experiment, model, Q, R, Qf, sat=None, du=None, max_iter=100,
         exit_condition=None, warm_start=True, qp_mode="qp", count=None, trace=None):
     """Receding-horizon loop restating mpc.py:128-304 for streaming == False (any clock.measure_freq),
-    with ``quad_program`` being the Riccati solver above (qp_mode "qp") or the lqr.py restatement
-    (qp_mode "lqr").  Keeps the quirks: u_prev from U_ref at steps 0 and 1 (:185), applied control
-    U_opt[:,0] (:250), target window lag (:276-277), exit codes 0/1/3 and the dropped last entry
+    with ``quad_program`` being the Riccati solver above (qp_mode "qp"), the lqr.py restatement
+    (qp_mode "lqr") or the exact box-constrained solve (qp_mode "exact", BVLS).  Keeps the quirks: u_prev from
+    U_ref at steps 0 and 1 (:185), applied control U_opt[:,0] (:250), target window lag (:276-277), exit codes 0/1/3 and the dropped last entry
     (:294-304).  ``count`` (a list) receives the number of QP solves per MPC step; ``trace`` (a list) receives
     (X_guess, U_guess) as they stand when each MPC step starts."""
     exit_code = 0
@@ -607,6 +607,8 @@ def mpc(x0, dim_u, order, X_targ, U_targ, clock, experiment, model, Q, R, Qf, sa
             x_now = experiment.lift(xs[step])
             if qp_mode == "lqr":
                 X_opt, U_opt, obj, _ = lqr_quad_program(x_now, X_ref, U_ref, Q_ls, R_ls, A_ls, B_ls, u_prev, sat, du)
+            elif qp_mode == "exact":
+                X_opt, U_opt, obj = exact_quad_program(x_now, X_ref, U_ref, Q_ls, R_ls, A_ls, B_ls, D_ls, u_prev, sat, du)
             else:
                 X_opt, U_opt, obj, _ = quad_program(x_now, X_ref, U_ref, Q_ls, R_ls, A_ls, B_ls, D_ls, u_prev, sat, du)
             if not np.isfinite(obj):

@@ -418,6 +418,41 @@ def test_closed_loop_vs_oracle(cfg, order, batch, horizon, path):
 
 
 @pytest.mark.parametrize("path", ["real", "complex"])
+@pytest.mark.parametrize("cfg,order,batch,horizon", [(1, 1, 2, None), (3, 1, 3, 16), (3, 2, 2, None), (4, 1, 2, 12)])
+def test_closed_loop_exact_qp_vs_oracle(cfg, order, batch, horizon, path):
+    """M4Q_QP_EXACT_BOX in the closed loop: every QP solved to the box-constrained optimum on the device (active-set
+    iteration on the Riccati factorisation) against the oracle's loop with the BVLS solve of the same QP.  Same SQP
+    iteration counts and exit codes; the first MPC step (all its SQP iterations) to 1e-9, the free-running 20-step
+    trajectory to 1e-4 of the bound (measured 1e-6 .. 1e-10: with exact solves the loop is far less sensitive than with
+    clipped ones).  Config 3 at order 2 runs at its own T = 40."""
+    p = configs.build(cfg, batch=batch, order=order, horizon=horizon)
+    idx = np.arange(batch)
+    res = _gpu_batch(p, idx, force_complex=(path == "complex"), exact_qp=True)
+    assert res["path"] == path
+    xs, us, codes, solves = _oracle_batch(p, idx, qp_mode="exact")
+    assert np.array_equal(res["exit_codes"], codes) and np.all(codes == 0)
+    assert np.array_equal(res["qp_solves"], solves)
+    assert rel(res["us"][:, :, 0], us[:, :, 0]) <= 1e-9
+    assert rel(res["xs"][:, :, 1], xs[:, :, 1]) <= 1e-9
+    assert np.abs(res["us"] - us).max() <= 1e-4 * p["sat"]
+    assert np.abs(res["xs"] - xs).max() <= 1e-4
+    assert np.abs(res["us"]).max() <= p["sat"] * (1 + 1e-15)
+    n_solves, sweeps, ratio_steps, end_kkt, end_precision, end_cap = res["qp_stats"]
+    assert n_solves == solves.sum() and end_kkt + end_precision == n_solves and end_cap == 0
+    assert sweeps >= n_solves
+    # and it matters: the clipped-Riccati loop lands elsewhere
+    clip = _gpu_batch(p, idx, force_complex=(path == "complex"))
+    assert np.abs(clip["us"] - res["us"]).max() > 1e-3 * p["sat"]
+    assert clip["qp_stats"] == (0, 0, 0, 0, 0, 0)
+
+
+def test_exact_qp_session_rejects_ref_lqr():
+    p = configs.build(1, batch=1)
+    with pytest.raises(_lib.M4qError):
+        _session(p, 1, qp_flags=_lib.QP_REF_LQR, exact_qp=True)
+
+
+@pytest.mark.parametrize("path", ["real", "complex"])
 @pytest.mark.parametrize("cfg,order,batch,horizon", [(1, 2, 1, None), (3, 1, 4, None), (4, 1, 2, 12)])
 def test_closed_loop_stepwise_teacher_forced(cfg, order, batch, horizon, path):
     """Every MPC step of the run, started from the ORACLE's state (states, controls, SQP guesses) through the
