@@ -298,6 +298,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
         atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 4, (unsigned long long)stats.end_kkt);
         atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 5, (unsigned long long)stats.end_precision);
         atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 6, (unsigned long long)stats.end_cap);
+        if (g == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 7, (unsigned long long)stats.wave_iters);
       }
       GView Xs = Xo, Us = Uo;
       Xs.off = in_a ? Xo.off : Xalt.off;

@@ -654,6 +654,7 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
 struct QpStats {   // per row, counted by the caller
   int newton = 0, arcs = 0;
   int end_kkt = 0, end_precision = 0, end_cap = 0;   // how the solve ended
+  int wave_iters = 0;                                 // iterations the wavefront went through (max over its rows)
 };
 
 // gradient of the objective at (Xk, Uk) and the working set.  Returns the number of entries of the working set that
@@ -847,6 +848,7 @@ __device__ __forceinline__ double solve_box_qp(const Prov& prov, int T, S x0, co
     }
     need_adj = false;
     face_min = false;
+    ++stats.wave_iters;
     riccati_backward<S, NX, NU, Prov, true>(prov, T, win, cost, flags, gains, j, going && lane_ok, &pin);
     wave_sync();
     RolloutInfo ri;
