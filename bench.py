@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="collective backend for N > 1: nccl (= RCCL over xGMI, the real thing) or "
                                                       "gloo (rehearsal on a box with fewer GPUs than ranks: results staged through the host)")
+    ap.add_argument("--force-dist", action="store_true", help="rehearsal: take the N > 1 code path (process group, torch-owned "
+                                                              "output buffers, gather) even with one rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -78,7 +80,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     torch = None
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -103,9 +106,9 @@ def main():
     per_model = p["scales"] is not None
 
     sess = EnsembleSession(B, n, m, p["order"], T, ns, p["dt"], p["sat"], p["du"], model_per_instance=per_model,
-                           target_cols=ns + T + 1, device=dev_index if world > 1 else -1)
+                           target_cols=ns + T + 1, device=dev_index if multi else -1)
     gather_bufs = None
-    if world > 1:
+    if multi:
         # results live in torch-owned HBM so RCCL can gather them without a copy
         us_t = torch.empty(B * ns * m, dtype=torch.float64, device="cuda")
         xs_t = torch.empty(B * (ns + 1) * n * 2, dtype=torch.float64, device="cuda")
@@ -123,7 +126,7 @@ def main():
 
     def one_step():
         sess.run(0, ns)
-        if world > 1:
+        if multi:
             sess.sync()
             us_t, us_all = gather_bufs
             xs_final = xs_t.view(B, ns + 1, n * 2)[:, -1, :].contiguous()
@@ -141,7 +144,7 @@ def main():
 
     def fence():
         sess.sync()
-        if world > 1:
+        if multi:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -161,7 +164,7 @@ def main():
     units_per_step = int(res["qp_solves"].astype(np.int64).sum()) * T
     ok = int((res["exit_codes"] == 0).sum())
     info = sess.info()
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed, float(units_per_step), float(ok)], dtype=torch.float64,
                          device="cuda" if args.backend == "nccl" else "cpu")
         tmax = t.clone()
@@ -211,7 +214,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(p)
         print(json.dumps(out))
     sess.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
