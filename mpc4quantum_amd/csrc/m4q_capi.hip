@@ -553,7 +553,7 @@ int m4q_session_qp_stats(m4q_session* s, int64_t* out6) {
   HIP_TRY(hipMemcpy(q, s->queue.p, sizeof(q), hipMemcpyDeviceToHost));
   for (int i = 0; i < 6; ++i) out6[i] = (int64_t)q[1 + i];
   if (std::getenv("M4Q_QP_TRACE"))
-    fprintf(stderr, "m4q: exact QP: %llu row sweeps, %llu wavefront iterations (x4 rows = %llu): lane efficiency %.2f\n", q[2], q[7],
+    fprintf(stderr, "m4q: exact QP: %llu row sweeps in %llu wavefront passes (x4 rows = %llu): lane efficiency %.2f\n", q[2], q[7],
             4 * q[7], q[7] ? (double)q[2] / (4.0 * (double)q[7]) : 0.0);
   return 0;
 }

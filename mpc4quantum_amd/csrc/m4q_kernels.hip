@@ -161,6 +161,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
   double uprev[NU];
 #pragma unroll
   for (int k = 0; k < NU; ++k) uprev[k] = 0.0;
+  BoxQpRow qp;                 // EXACT: the box-QP solve this row has in progress (spans iterations of the loop below)
+  int qp_passes = 0;           // passes of this wavefront through the solver iteration (statistics)
   GView xt = gview(x_targ, 0, 0), ut = gview(a.u_targ, 0, 0), op0 = gview(a.op0, 0, 0), ops = gview(a.ops, 0, 0);
   wave_sync();
 
@@ -244,7 +246,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
       }
       wave_sync();
     }
-    if (!__any(active || pending)) break;
+    if (!__any(active || pending)) {
+      if (EXACT && threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 7, (unsigned long long)qp_passes);
+      break;
+    }
     if (!__any(active)) {
       __builtin_amdgcn_s_sleep(8);                 // only tail items whose head is still running: poll again
       continue;
@@ -272,42 +277,56 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
 #endif
     // M4Q_EXP: timing-only ablation builds (results are wrong): 1 fixed 3 SQP iterations, 2 no backward,
     // 4 no forward, 8 no line search, 16 no guess update, 32 no plant/shift
-    if constexpr (!(M4Q_EXP & 2)) riccati_backward<S, NX, NU>(prov, T, win, cost, a.flags, gains, j, st);
+    if constexpr (!EXACT && !(M4Q_EXP & 2)) riccati_backward<S, NX, NU>(prov, T, win, cost, a.flags, gains, j, st);
     wave_sync();
     double uapp[NU];
 #pragma unroll
     for (int k = 0; k < NU; ++k) uapp[k] = 0.0;
     double chk = 0.0;
+    // `solved`: the rows whose QP is solved in this pass and that go on to the line search / update / plant below.
+    // Clipped mode: every running row, each pass.  EXACT: a row's solve spans several passes (one active-set iteration
+    // per pass), so that no row waits for the slowest solve of its wavefront.
+    bool solved = running;
     if constexpr (EXACT) {
-      // start from the current SQP guess (the shifted previous solution on warm steps: nearly the right working
-      // set), clipped into the box and rolled out through the linearised model; then projected Newton to the optimum
-      // of the box-constrained QP.  The linearisation point (Xg, Ug) must stay untouched until the solve is over.
-      Box box;
-      box.sat = a.sat;
-      chk = rollout_arc<S, NX, NU>(prov, T, x_cur, win, cost, Ug, Ug, 0.0, box, lo0, hi0, Xo, Uo, j, st);
-      wave_sync();
-      const bool go = running && finite_d(chk);
-      bool in_a = true;
-      QpStats stats;
-      chk = solve_box_qp<S, NX, NU>(prov, T, x_cur, win, cost, a.flags, gains, box, lo0, hi0, Xo, Uo, Xalt, Ualt, pin_stat, chk, go,
-                                    j, jj, lane_ok, in_a, stats);
-      if (running && jj == 0) {
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 1, 1ull);
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 2, (unsigned long long)stats.newton);
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 3, (unsigned long long)stats.arcs);
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 4, (unsigned long long)stats.end_kkt);
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 5, (unsigned long long)stats.end_precision);
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 6, (unsigned long long)stats.end_cap);
-        if (g == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 7, (unsigned long long)stats.wave_iters);
+      PinCtx<NU> pin;
+      pin.stat = pin_stat;
+      pin.box.sat = a.sat;
+#pragma unroll
+      for (int k = 0; k < NU; ++k) { pin.lo0[k] = lo0[k]; pin.hi0[k] = hi0[k]; }
+      // rows starting a solve: the current SQP guess (the shifted previous solution on warm steps: nearly the right
+      // working set), clipped into the box and rolled out through the linearised model.  The linearisation point
+      // (Xg, Ug) stays untouched until the solve is over.
+      const bool start = running && !qp.busy;
+      double J0 = 0.0;
+      if (__any(start)) {
+        J0 = rollout_arc<S, NX, NU>(prov, T, x_cur, win, cost, Ug, Ug, 0.0, pin.box, lo0, hi0, Xo, Uo, j, start && lane_ok);
+        wave_sync();
       }
+      bool bad_start = false;
+      if (start) {
+        qp.begin(J0);
+        if (!finite_d(J0)) { qp.busy = false; bad_start = true; }
+      }
+      if (__any(qp.busy)) ++qp_passes;
+      const bool ended = box_qp_iterate<S, NX, NU>(prov, T, x_cur, win, cost, a.flags, gains, pin, Xo, Uo, Xalt, Ualt, qp, j, jj, lane_ok);
+      solved = running && (ended || bad_start);
+      chk = qp.Jk;
       GView Xs = Xo, Us = Uo;
-      Xs.off = in_a ? Xo.off : Xalt.off;
-      Us.off = in_a ? Uo.off : Ualt.off;
-      if (go) {
+      Xs.off = qp.cur_is_a ? Xo.off : Xalt.off;
+      Us.off = qp.cur_is_a ? Uo.off : Ualt.off;
+      if (solved && jj == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 1, 1ull);
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 2, (unsigned long long)qp.stats.newton);
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 3, (unsigned long long)qp.stats.arcs);
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 4, (unsigned long long)qp.stats.end_kkt);
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 5, (unsigned long long)qp.stats.end_precision);
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 6, (unsigned long long)qp.stats.end_cap);
+      }
+      if (solved && !bad_start) {
 #pragma unroll
         for (int k = 0; k < NU; ++k) uapp[k] = Us.ld<double>(k);
         if (use_ls) {
-          if (!in_a) {
+          if (!qp.cur_is_a) {
             if (lane_ok)
               for (int t = 0; t <= T; ++t) Xo.st<S>(t * NX + j, Xs.ld<S>(t * NX + j));
             for (int e = jj; e < T * NU; e += 16) Uo.st<double>(e, Us.ld<double>(e));
@@ -326,10 +345,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
     }
     wave_sync();
     const bool fail = !finite_d(chk);                      // mpc.py:200-203
-    if (running) ++iter;
+    if (solved) ++iter;
     double alpha = 1.0;
     bool fin = true;
-    if (!(M4Q_EXP & 8) && __any(running && use_ls)) {
+    if (!(M4Q_EXP & 8) && __any(solved && use_ls)) {
       ZView<NX, NU> z;
       z.T = T; z.Xg = Xg; z.Xo = Xo; z.Xt = win.xbm; z.Ug = Ug; z.Uo = Uo; z.Ut = win.ubm;
       double al = 1.0, stepn = 0.0;
@@ -342,7 +361,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
     }
     if (M4Q_EXP & 1) { fin = !use_ls || iter >= 3; alpha = 1.0; }
     wave_sync();
-    const bool upd = running && !fail && use_ls;      // warm steps wrote the shifted guess in the rollout
+    const bool upd = solved && !fail && use_ls;       // warm steps wrote the shifted guess in the rollout
     // X_guess += alpha (X_opt - X_guess) (mpc.py:228-229)
     // (these small per-element passes are latency bound: unrolled so that several loads are in flight)
     if (!(M4Q_EXP & 16) && upd && lane_ok) {
@@ -359,7 +378,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
         Ug.st<double>(e, ug + alpha * (Uo.ld<double>(e) - ug));
       }
     }
-    const bool step_done = running && (fail || fin || iter >= a.max_iter);
+    const bool step_done = solved && (fail || fin || iter >= a.max_iter);
     wave_sync();
 
     // ---- rows that finished their MPC step: apply, propagate, shift ----
@@ -583,15 +602,19 @@ __global__ __launch_bounds__(64) M4Q_OCC void qp_kernel(QpArgs a) {
           for (int i = 0; i < T * NU; ++i) Ua.st<double>(i, Uo.ld<double>(i));
       }
       wave_sync();
-      Box box;
-      box.sat = a.sat;
-      bool in_a;
-      QpStats stats;
-      obj_out = solve_box_qp<cplx, NX, NU>(prov, T, x0, win, cost, a.flags, gains, box, lo0, hi0, Xa, Ua, Xb, Ub, stat, obj, valid,
-                                           j, jj, L.lane_ok, in_a, stats);
+      PinCtx<NU> pin;
+      pin.stat = stat;
+      pin.box.sat = a.sat;
+#pragma unroll
+      for (int k = 0; k < NU; ++k) { pin.lo0[k] = lo0[k]; pin.hi0[k] = hi0[k]; }
+      BoxQpRow row;
+      if (valid) row.begin(obj);
+      while (__any(row.busy)) box_qp_iterate<cplx, NX, NU>(prov, T, x0, win, cost, a.flags, gains, pin, Xa, Ua, Xb, Ub, row, j, jj, L.lane_ok);
+      obj_out = row.Jk;
+      const QpStats& stats = row.stats;
       GView Xs = Xa, Us = Ua;
-      Xs.off = in_a ? Xa.off : Xb.off;
-      Us.off = in_a ? Ua.off : Ub.off;
+      Xs.off = row.cur_is_a ? Xa.off : Xb.off;
+      Us.off = row.cur_is_a ? Ua.off : Ub.off;
       if (st) {
         for (int t = 0; t <= T; ++t) Xo.st<cplx>(t * NX + j, Xs.ld<cplx>(t * NX + j));
         if (j == 0)

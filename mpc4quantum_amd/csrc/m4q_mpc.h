@@ -654,7 +654,6 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
 struct QpStats {   // per row, counted by the caller
   int newton = 0, arcs = 0;
   int end_kkt = 0, end_precision = 0, end_cap = 0;   // how the solve ended
-  int wave_iters = 0;                                 // iterations the wavefront went through (max over its rows)
 };
 
 // gradient of the objective at (Xk, Uk) and the working set.  Returns the number of entries of the working set that
@@ -812,77 +811,89 @@ __device__ __forceinline__ double rollout_arc(const Prov& prov, int T, S x0, con
   return rowsum<NX>(cx) + cu;
 }
 
-// The exact solve for the four rows of a wavefront.  On entry (Xa, Ua) hold a feasible point with its linearised
-// trajectory and Ja its objective; the two buffer pairs (Xa, Ua) / (Xb, Ub) - which must share their wave-uniform
-// bases - ping-pong, `cur_is_a` tells which one holds the answer on exit.  `act` marks the rows that take part.
-// Returns the objective of the answer.
-template <class S, int NX, int NU, class Prov>
-__device__ __forceinline__ double solve_box_qp(const Prov& prov, int T, S x0, const Window& win, const CostRef<S>& cost, int flags,
-                                               const GView& gains, const Box& box, const double (&lo0)[NU],
-                                               const double (&hi0)[NU], GView Xa, GView Ua, GView Xb, GView Ub, const GView& stat,
-                                               double Ja, bool act, int j, int jj, bool lane_ok, bool& cur_is_a, QpStats& stats) {
-  bool going = act;
-  bool need_adj = true;          // the working set has to be (re-)derived from the gradient at the iterate
-  bool face_min = false;         // the iterate minimises J over the face of the working set in `stat`
-  int stalls = 0;
-  double Jk = Ja;
-  cur_is_a = true;
-  PinCtx<NU> pin;
-  pin.stat = stat;
-  pin.box = box;
-#pragma unroll
-  for (int k = 0; k < NU; ++k) { pin.lo0[k] = lo0[k]; pin.hi0[k] = hi0[k]; }
-  for (int it = 0; it < 100 && __any(going); ++it) {
-    // per-row source / destination: same wave-uniform bases, lane offsets swapped
-    GView Xk = Xa, Uk = Ua, Xc = Xb, Uc = Ub;
-    Xk.off = cur_is_a ? Xa.off : Xb.off;
-    Uk.off = cur_is_a ? Ua.off : Ub.off;
-    Xc.off = cur_is_a ? Xb.off : Xa.off;
-    Uc.off = cur_is_a ? Ub.off : Ua.off;
-    if (__any(going && need_adj)) {
-      const bool adj = going && need_adj;
-      const int nchg = adjoint_working_set<S, NX, NU>(prov, T, win, cost, Xk, Uk, pin, j, adj && lane_ok);
-      wave_sync();
-      if (adj && face_min && nchg == 0) { going = false; ++stats.end_kkt; }   // face minimiser, multipliers of the right sign
-      if (!__any(going)) break;
-    }
-    need_adj = false;
+// Per-row state of a box-QP solve in progress (uniform inside a row).  The buffers: two trajectory pairs
+// (Xa, Ua) / (Xb, Ub) - which must share their wave-uniform bases, rows pick theirs by lane offset - ping-pong;
+// `cur_is_a` tells which one holds the iterate (and, once `busy` drops, the answer).
+struct BoxQpRow {
+  bool busy = false;
+  bool need_adj = true;    // the working set has to be (re-)derived from the gradient at the iterate
+  bool face_min = false;   // the iterate minimises J over the face of the working set in `stat`
+  bool cur_is_a = true;
+  int stalls = 0, iters = 0;
+  double Jk = 0.0;
+  QpStats stats;
+  // (Xa, Ua) hold a feasible point with its linearised trajectory, J its objective
+  __device__ __forceinline__ void begin(double J) {
+    busy = true;
+    need_adj = true;
     face_min = false;
-    ++stats.wave_iters;
+    cur_is_a = true;
+    stalls = 0;
+    iters = 0;
+    Jk = J;
+    stats = QpStats();
+  }
+};
+
+// One iteration of the exact solve for the rows of the wavefront that have one in progress (r.busy).  Returns true for
+// the rows whose solve ended in this call: r.Jk is then the objective of the answer, r.cur_is_a says where it is.
+template <class S, int NX, int NU, class Prov>
+__device__ __forceinline__ bool box_qp_iterate(const Prov& prov, int T, S x0, const Window& win, const CostRef<S>& cost, int flags,
+                                               const GView& gains, const PinCtx<NU>& pin, GView Xa, GView Ua, GView Xb, GView Ub,
+                                               BoxQpRow& r, int j, int jj, bool lane_ok) {
+  const bool was_busy = r.busy;
+  const Box& box = pin.box;
+  // per-row source / destination: same wave-uniform bases, lane offsets swapped
+  GView Xk = Xa, Uk = Ua, Xc = Xb, Uc = Ub;
+  Xk.off = r.cur_is_a ? Xa.off : Xb.off;
+  Uk.off = r.cur_is_a ? Ua.off : Ub.off;
+  Xc.off = r.cur_is_a ? Xb.off : Xa.off;
+  Uc.off = r.cur_is_a ? Ub.off : Ua.off;
+  if (__any(r.busy && r.need_adj)) {
+    const bool adj = r.busy && r.need_adj;
+    const int nchg = adjoint_working_set<S, NX, NU>(prov, T, win, cost, Xk, Uk, pin, j, adj && lane_ok);
+    wave_sync();
+    if (adj && r.face_min && nchg == 0) { r.busy = false; ++r.stats.end_kkt; }   // face minimiser, multipliers of the right sign
+  }
+  if (__any(r.busy)) {
+    const bool going = r.busy;
+    r.need_adj = false;
+    r.face_min = false;
+    if (going) ++r.iters;
     riccati_backward<S, NX, NU, Prov, true>(prov, T, win, cost, flags, gains, j, going && lane_ok, &pin);
     wave_sync();
     RolloutInfo ri;
     const double Jc = rollout_policy<S, NX, NU>(prov, T, x0, win, cost, gains, pin, Uk, true, Xc, Uc, j, going && lane_ok, ri);
     wave_sync();
-    if (going) ++stats.newton;
+    if (going) ++r.stats.newton;
     bool moved = false;
     if (going && !(ri.dmax > 1e-13 * box.sat)) {
       // the policy reproduces the iterate: it is the minimiser of its face (or NaN)
-      if (!(ri.dmax == ri.dmax) || ++stalls > 1) { going = false; ++stats.end_precision; }
-      face_min = true;
-      need_adj = true;
-    } else if (going && (Jc < Jk || (!ri.outside && Jc <= Jk + 1e-12 * fabs(Jk) && stalls < 2))) {
+      if (!(ri.dmax == ri.dmax) || ++r.stalls > 1) { r.busy = false; ++r.stats.end_precision; }
+      r.face_min = true;
+      r.need_adj = true;
+    } else if (going && (Jc < r.Jk || (!ri.outside && Jc <= r.Jk + 1e-12 * fabs(r.Jk) && r.stalls < 2))) {
       // (a face minimiser is taken even without a visible decrease: near the optimum J is flat to working precision
       //  long before the controls are, and the Newton point is the more accurate of the two)
-      stalls = Jc < Jk ? 0 : stalls + 1;
+      r.stalls = Jc < r.Jk ? 0 : r.stalls + 1;
       moved = true;
-      Jk = Jc;
-      face_min = !ri.outside;
-      need_adj = true;
+      r.Jk = Jc;
+      r.face_min = !ri.outside;
+      r.need_adj = true;
     } else if (going && !ri.outside) {
-      going = false;                                           // face minimiser without decrease: working precision
-      ++stats.end_precision;
+      r.busy = false;                                          // face minimiser without decrease: working precision
+      ++r.stats.end_precision;
     }
     // classical step for the rows whose clipped rollout did not decrease J
-    const bool ratio = going && !moved && !face_min;
+    const bool ratio = r.busy && going && !moved && !r.face_min;
     if (__any(ratio)) {
       RolloutInfo rn;
       const double Jn = rollout_policy<S, NX, NU>(prov, T, x0, win, cost, gains, pin, Uk, false, Xc, Uc, j, ratio && lane_ok, rn);
       wave_sync();
       if (ratio) {
-        ++stats.arcs;
+        ++r.stats.arcs;
         const double al = rn.alpha;
-        // blend in place: trial = iterate + al (Newton - iterate); the blocking control lands exactly on its bound
+        // blend in place: trial = iterate + al (Newton - iterate); blocking controls land exactly on their bound
         if (lane_ok) {
 #pragma unroll 4
           for (int t = 0; t <= T; ++t) {
@@ -894,27 +905,27 @@ __device__ __forceinline__ double solve_box_qp(const Prov& prov, int T, S x0, co
           const double uk = Uk.ld<double>(e), un = Uc.ld<double>(e);
           double v = fma(al, un - uk, uk);
           double lo, hi;
-          box.at<NU>(e / NU, e % NU, lo0, hi0, lo, hi);
+          box.at<NU>(e / NU, e % NU, pin.lo0, pin.hi0, lo, hi);
           const bool above = un > hi, below = un < lo;
           if ((above || below) && ((above ? hi : lo) - uk) / (un - uk) <= al + 1e-14) {
             v = above ? hi : lo;                               // blocking: lands exactly on its bound and is pinned
-            stat.st<double>(e, above ? 1.0 : -1.0);
+            pin.stat.template st<double>(e, above ? 1.0 : -1.0);
           }
           Uc.st<double>(e, v);
         }
-        const double r = 1.0 - al;
-        Jk = fma(Jk - Jn, r * r, Jn);                          // J along the segment to the face minimiser
+        const double q = 1.0 - al;
+        r.Jk = fma(r.Jk - Jn, q * q, Jn);                      // J along the segment to the face minimiser
         moved = true;
-        // al == 0 (degenerate): a free control sits on the bound the step wants to cross; it is pinned now, nothing moved
-        stalls = al > 0.0 ? 0 : stalls + 1;
-        if (stalls > 2 * NU * T) { going = false; ++stats.end_cap; }
+        // al == 0 (degenerate): free controls sit on the bound the step wants to cross; they are pinned now, nothing moved
+        r.stalls = al > 0.0 ? 0 : r.stalls + 1;
+        if (r.stalls > 2 * NU * T) { r.busy = false; ++r.stats.end_cap; }
       }
     }
-    if (going && moved) cur_is_a = !cur_is_a;
+    if (going && moved) r.cur_is_a = !r.cur_is_a;
+    if (r.busy && r.iters >= 100) { r.busy = false; ++r.stats.end_cap; }
     wave_sync();
   }
-  if (going) ++stats.end_cap;
-  return Jk;
+  return was_busy && !r.busy;
 }
 
 // ---------------------------------------------------------------------------------------------
