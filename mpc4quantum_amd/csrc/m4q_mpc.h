@@ -331,6 +331,13 @@ struct PinCtx {
   GView stat;
   Box box;
   double lo0[NU], hi0[NU];
+  // derive (per row): the sweep first re-derives this row's working set from the gradient at the iterate (Xk, Uk) - the
+  // adjoint recursion lam_t = Q e_t + A_t^H lam_{t+1}, g_t = R (u_t - ub_t) + Re B_t^H lam_{t+1} runs inside the sweep:
+  // a control is pinned iff it sits on a bound with the gradient pushing outward.  any_derive: some row of the wavefront
+  // does (uniform).  nchg receives the number of entries that changed with respect to what `stat` held.
+  bool derive = false, any_derive = false;
+  GView Xk, Uk;
+  int nchg = 0;
   // pinned value of control k at horizon index t, or free
   __device__ __forceinline__ bool pinned(int t, int k, double& value) const {
     const double st = stat.ld<double>(t * NU + k);
@@ -343,7 +350,7 @@ struct PinCtx {
 
 template <class S, int NX, int NU, class Prov, bool PINNED = false>
 __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const Window& win, const CostRef<S>& cost, int flags,
-                                                  const GView& gains, int j, bool store_ok, const PinCtx<NU>* pin = nullptr) {
+                                                  const GView& gains, int j, bool store_ok, PinCtx<NU>* pin = nullptr) {
   const bool ref = (flags & QP_REF_LQR) != 0;
   S Pc[NX];
   S pv = zero_of<S>();
@@ -353,6 +360,11 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
 #pragma unroll
     for (int i = 0; i < NX; ++i) Pc[i] = Qt[i * NX + j];
     if (ref) pv = cneg(qrow_times<NX>(Qt, xb_next, j));
+  }
+  S lam = zero_of<S>();        // PINNED + derive: adjoint of the iterate's trajectory
+  if constexpr (PINNED) {
+    pin->nchg = 0;
+    if (pin->any_derive) lam = qrow_times<NX>(cost.q(T, T), csub(pin->Xk.template ld<S>(T * NX + j), xb_next), j);
   }
   // operands of horizon index t are fetched while index t+1 is being worked on
   typename Prov::Lin lin = prov.fetch(T - 1);
@@ -415,11 +427,40 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
     if constexpr (PINNED) {
       // controls pinned at a bound are constants of the stage: K row = [0 | du_fix]; the free ones respond to them:
       //   G_ff du_f = -(H_f dx + h_f + G_fp du_p)
+      double stv[NU];
+#pragma unroll
+      for (int k = 0; k < NU; ++k) stv[k] = pin->stat.template ld<double>(t * NU + k);
+      if (pin->any_derive) {
+        double uk[NU];
+#pragma unroll
+        for (int k = 0; k < NU; ++k) uk[k] = pin->Uk.template ld<double>(t * NU + k);
+#pragma unroll
+        for (int k = 0; k < NU; ++k) {
+          double gk = rowsum<NX>(real_of(cmul(cconj(Brow[k]), lam)));
+#pragma unroll
+          for (int l = 0; l < NU; ++l) gk = fma(real_of(Rt[k * NU + l]), uk[l] - ub[l], gk);
+          double lo, hi;
+          pin->box.template at<NU>(t, k, pin->lo0, pin->hi0, lo, hi);
+          const double eps = 1e-12 * pin->box.sat;
+          double sv = 0.0;
+          if (uk[k] <= lo + eps && gk > 0.0) sv = -1.0;
+          if (uk[k] >= hi - eps && gk < 0.0) sv = 1.0;
+          if (hi - lo <= 2 * eps) sv = 1.0;                // degenerate interval: nothing to optimise
+          if (pin->derive) {
+            pin->nchg += stv[k] != sv ? 1 : 0;
+            stv[k] = sv;
+            if (store_ok && j == 0) pin->stat.template st<double>(t * NU + k, sv);
+          }
+        }
+        const S e = csub(pin->Xk.template ld<S>(t * NX + j), xb);
+        lam = dot_lane_index<false, true, NX>(lam, Ac, qrow_times<NX>(cost.q(t, T), e, j));   // Q_t e_t + A_t^H lam
+      }
 #pragma unroll
       for (int k = 0; k < NU; ++k) {
-        double v;
-        fix[k] = pin->pinned(t, k, v);
-        dufix[k] = fix[k] ? v - ub[k] : 0.0;
+        double lo, hi;
+        pin->box.template at<NU>(t, k, pin->lo0, pin->hi0, lo, hi);
+        fix[k] = stv[k] != 0.0;
+        dufix[k] = fix[k] ? (stv[k] > 0.0 ? hi : lo) - ub[k] : 0.0;
       }
 #pragma unroll
       for (int k = 0; k < NU; ++k) {
@@ -646,8 +687,8 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
 //      on a bound the Newton step wants to cross, common with these stiff Hessians) they would otherwise come one per
 //      sweep.  J(a) = J_N + (J^k - J_N)(1 - a)^2 along the segment, so this always decreases J and needs no
 //      evaluation; trajectories blend linearly;
-//   4. W is re-derived from the gradient (adjoint sweep: a control on a bound with the gradient pushing outward is
-//      pinned, all others free) after 2; kept, plus the blocking control, after 3.
+//   4. W is re-derived from the gradient (adjoint recursion, run inside the next Riccati sweep: a control on a bound
+//      with the gradient pushing outward is pinned, all others free) after 2; kept, plus the blocking controls, after 3.
 // Converged when a face minimiser is followed by an unchanged working set (multipliers of the right sign = KKT).
 // J decreases strictly from iterate to iterate, so no face is visited twice.
 // ---------------------------------------------------------------------------------------------
@@ -655,46 +696,6 @@ struct QpStats {   // per row, counted by the caller
   int newton = 0, arcs = 0;
   int end_kkt = 0, end_precision = 0, end_cap = 0;   // how the solve ended
 };
-
-// gradient of the objective at (Xk, Uk) and the working set.  Returns the number of entries of the working set that
-// changed with respect to what `stat` held (replicated over the row).
-template <class S, int NX, int NU, class Prov>
-__device__ __forceinline__ int adjoint_working_set(const Prov& prov, int T, const Window& win, const CostRef<S>& cost, const GView& Xk,
-                                                    const GView& Uk, const PinCtx<NU>& pin, int j, bool store_ok) {
-  // lam = Q_T e_T ;  g_t = 2 (R (u_t - ub_t) + Re B_t^H lam_{t+1}) ;  lam_t = Q_t e_t + A_t^H lam_{t+1}
-  S lam = qrow_times<NX>(cost.q(T, T), csub(Xk.ld<S>(T * NX + j), win.xbm.ld<S>(T * NX + j)), j);
-  int nchg = 0;
-  for (int t = T - 1; t >= 0; --t) {
-    M4Q_NO_HOIST();
-    const typename Prov::Lin lin = prov.fetch(t);
-    S Ac[NX];
-    prov.col(lin, Ac);
-    S av, Brow[NU], dlt;
-    prov.rows(lin, lam, av, Brow, dlt);
-    const S* Rt = cost.r(t);
-    double u[NU], ub[NU];
-#pragma unroll
-    for (int k = 0; k < NU; ++k) { u[k] = Uk.ld<double>(t * NU + k); ub[k] = win.ubm.ld<double>(t * NU + k); }
-#pragma unroll
-    for (int k = 0; k < NU; ++k) {
-      double gk = rowsum<NX>(real_of(cmul(cconj(Brow[k]), lam)));
-#pragma unroll
-      for (int l = 0; l < NU; ++l) gk = fma(real_of(Rt[k * NU + l]), u[l] - ub[l], gk);
-      double lo, hi;
-      pin.box.template at<NU>(t, k, pin.lo0, pin.hi0, lo, hi);
-      const double eps = 1e-12 * pin.box.sat;
-      double st = 0.0;
-      if (u[k] <= lo + eps && gk > 0.0) st = -1.0;
-      if (u[k] >= hi - eps && gk < 0.0) st = 1.0;
-      if (hi - lo <= 2 * eps) st = 1.0;                  // degenerate interval: nothing to optimise
-      nchg += pin.stat.template ld<double>(t * NU + k) != st ? 1 : 0;
-      if (store_ok && j == 0) pin.stat.template st<double>(t * NU + k, st);
-    }
-    const S e = csub(Xk.ld<S>(t * NX + j), win.xbm.ld<S>(t * NX + j));
-    lam = dot_lane_index<false, true, NX>(lam, Ac, qrow_times<NX>(cost.q(t, T), e, j));     // Q_t e_t + A_t^H lam
-  }
-  return nchg;
-}
 
 // What a policy rollout reports besides the objective (all replicated over the row).
 struct RolloutInfo {
@@ -839,7 +840,7 @@ struct BoxQpRow {
 // the rows whose solve ended in this call: r.Jk is then the objective of the answer, r.cur_is_a says where it is.
 template <class S, int NX, int NU, class Prov>
 __device__ __forceinline__ bool box_qp_iterate(const Prov& prov, int T, S x0, const Window& win, const CostRef<S>& cost, int flags,
-                                               const GView& gains, const PinCtx<NU>& pin, GView Xa, GView Ua, GView Xb, GView Ub,
+                                               const GView& gains, PinCtx<NU>& pin, GView Xa, GView Ua, GView Xb, GView Ub,
                                                BoxQpRow& r, int j, int jj, bool lane_ok) {
   const bool was_busy = r.busy;
   const Box& box = pin.box;
@@ -849,19 +850,21 @@ __device__ __forceinline__ bool box_qp_iterate(const Prov& prov, int T, S x0, co
   Uk.off = r.cur_is_a ? Ua.off : Ub.off;
   Xc.off = r.cur_is_a ? Xb.off : Xa.off;
   Uc.off = r.cur_is_a ? Ub.off : Ua.off;
-  if (__any(r.busy && r.need_adj)) {
-    const bool adj = r.busy && r.need_adj;
-    const int nchg = adjoint_working_set<S, NX, NU>(prov, T, win, cost, Xk, Uk, pin, j, adj && lane_ok);
-    wave_sync();
-    if (adj && r.face_min && nchg == 0) { r.busy = false; ++r.stats.end_kkt; }   // face minimiser, multipliers of the right sign
-  }
   if (__any(r.busy)) {
+    const bool going0 = r.busy;
+    // the sweep re-derives the working set of the rows that need it (adjoint recursion inside the sweep)
+    const bool adj = r.busy && r.need_adj;
+    pin.derive = adj;
+    pin.any_derive = __any(adj);
+    pin.Xk = Xk;
+    pin.Uk = Uk;
+    if (going0) ++r.iters;
+    riccati_backward<S, NX, NU, Prov, true>(prov, T, win, cost, flags, gains, j, going0 && lane_ok, &pin);
+    wave_sync();
+    if (adj && r.face_min && pin.nchg == 0) { r.busy = false; ++r.stats.end_kkt; }   // face minimiser, multipliers of the right sign
     const bool going = r.busy;
     r.need_adj = false;
     r.face_min = false;
-    if (going) ++r.iters;
-    riccati_backward<S, NX, NU, Prov, true>(prov, T, win, cost, flags, gains, j, going && lane_ok, &pin);
-    wave_sync();
     RolloutInfo ri;
     const double Jc = rollout_policy<S, NX, NU>(prov, T, x0, win, cost, gains, pin, Uk, true, Xc, Uc, j, going && lane_ok, ri);
     wave_sync();
