@@ -49,8 +49,9 @@ struct QpArgs {
   const cplx* A_ls; const cplx* B_ls; const cplx* D_ls;
   const double* u_prev;
   cplx* X_opt; double* U_opt; double* cost; cplx* gains;   // gains: caller buffer or workspace [B][T][n+1][m]
-  // QP_EXACT_BOX workspace: alternate trajectory pair, working set [B][T][m], Newton point [B][T][m], iteration counts [B]
-  cplx* X_alt; double* U_alt; double* pin_stat; double* U_newton; int* newton_iters;
+  // QP_EXACT_BOX workspace: two trajectory pairs in one allocation each (X_alt [2][B][T+1][n], U_alt [2][B][T][m]),
+  // working set [B][T][m], sweeps per instance [B] (diagnostic, may be null)
+  cplx* X_alt; double* U_alt; double* pin_stat; int* sweep_counts;
 };
 
 // discretize_homogeneous for B generator sets (vectorize.py:8-49).  gens: S [B|1][1+m][n][n] (row-major), scaled per

@@ -283,9 +283,9 @@ int m4q_session_create(const m4q_problem* p, int32_t B, int32_t device, m4q_sess
   long resident = (long)per_cu * prop.multiProcessorCount;
   s->grid = (int)(nquads < resident ? nquads : resident);
   const size_t rows = (size_t)s->grid * 4;
-  // [Xg rows][Xo rows] and [Ug rows][Uo rows]; the exact QP adds [Xalt rows] and [Ualt][working set][Newton point]
+  // [Xg rows][Xo rows] and [Ug rows][Uo rows]; the exact QP adds [Xalt rows] and [Ualt rows][working-set rows]
   if (!rc) rc = s->wsXg.alloc((exact ? 3 : 2) * rows * (T + 1) * n * C);
-  if (!rc) rc = s->wsUg.alloc((exact ? 5 : 2) * rows * T * m * 8);
+  if (!rc) rc = s->wsUg.alloc((exact ? 4 : 2) * rows * T * m * 8);
   if (!rc) rc = s->queue.alloc(64);
   if (!rc) rc = s->head_done.alloc((size_t)B * 4);
   if (!rc) rc = s->wsG.alloc(rows * T * (n + 1) * m * C);
@@ -672,17 +672,16 @@ int m4q_quad_program_batch(int32_t B, int32_t dim_x, int32_t dim_u, int32_t T, i
   a.A_ls = (const cplx*)d_a; a.B_ls = (const cplx*)d_b; a.D_ls = (const cplx*)d_d; a.u_prev = (const double*)d_up;
   a.X_opt = (cplx*)d_xo; a.U_opt = (double*)d_uo; a.cost = (double*)d_c; a.gains = (cplx*)d_g;
   if (qp_flags & M4Q_QP_EXACT_BOX) {
-    void *d_xa, *d_ua, *d_st, *d_un;
+    void *d_xa, *d_ua, *d_st;
     if ((double)B * (T + 1) * n * C * 2 >= 4294967296.0)
       return fail(M4Q_E_BADARG, "M4Q_QP_EXACT_BOX: batch too large for one call (trajectory workspace must stay below 4 GiB)");
     if ((rc = t.up(nullptr, 2 * (size_t)B * (T + 1) * n * C, &d_xa))) return rc;
     if ((rc = t.up(nullptr, 2 * (size_t)B * T * m * 8, &d_ua))) return rc;
     if ((rc = t.up(nullptr, (size_t)B * T * m * 8, &d_st))) return rc;
-    if ((rc = t.up(nullptr, (size_t)B * T * m * 8, &d_un))) return rc;
-    a.X_alt = (cplx*)d_xa; a.U_alt = (double*)d_ua; a.pin_stat = (double*)d_st; a.U_newton = (double*)d_un;
+    a.X_alt = (cplx*)d_xa; a.U_alt = (double*)d_ua; a.pin_stat = (double*)d_st;
     if (getenv("M4Q_QP_TRACE")) {
       if ((rc = t.up(nullptr, (size_t)B * 4, &d_it))) return rc;
-      a.newton_iters = (int*)d_it;
+      a.sweep_counts = (int*)d_it;
     }
   }
   rc = sh->launch_qp(a, nullptr);
@@ -694,7 +693,7 @@ int m4q_quad_program_batch(int32_t B, int32_t dim_x, int32_t dim_u, int32_t T, i
     long sum = 0;
     int mx = 0;
     for (int v : it) { sum += v; mx = v > mx ? v : mx; }
-    fprintf(stderr, "m4q: exact box QP: %d instances, Newton iterations mean %.2f max %d\n", B, (double)sum / B, mx);
+    fprintf(stderr, "m4q: exact box QP: %d instances, pinned sweeps mean %.2f max %d\n", B, (double)sum / B, mx);
   }
   if ((rc = down(X_opt, d_xo, (size_t)B * (T + 1) * n * C))) return rc;
   if ((rc = down(U_opt, d_uo, (size_t)B * T * m * 8))) return rc;

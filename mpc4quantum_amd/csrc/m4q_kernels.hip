@@ -299,7 +299,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
       const bool start = running && !qp.busy;
       double J0 = 0.0;
       if (__any(start)) {
-        J0 = rollout_arc<S, NX, NU>(prov, T, x_cur, win, cost, Ug, Ug, 0.0, pin.box, lo0, hi0, Xo, Uo, j, start && lane_ok);
+        J0 = rollout_open<S, NX, NU>(prov, T, x_cur, win, cost, Ug, pin.box, lo0, hi0, Xo, Uo, j, start && lane_ok);
         wave_sync();
       }
       bool bad_start = false;
@@ -316,8 +316,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
       Us.off = qp.cur_is_a ? Uo.off : Ualt.off;
       if (solved && jj == 0) {
         atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 1, 1ull);
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 2, (unsigned long long)qp.stats.newton);
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 3, (unsigned long long)qp.stats.arcs);
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 2, (unsigned long long)qp.stats.sweeps);
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 3, (unsigned long long)qp.stats.ratio_steps);
         atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 4, (unsigned long long)qp.stats.end_kkt);
         atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 5, (unsigned long long)qp.stats.end_precision);
         atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 6, (unsigned long long)qp.stats.end_cap);
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(64) M4Q_OCC void qp_kernel(QpArgs a) {
         if (j == 0)
           for (int i = 0; i < T * NU; ++i) Uo.st<double>(i, Us.ld<double>(i));
       }
-      if (valid && jj == 0 && a.newton_iters) a.newton_iters[b] = stats.newton;
+      if (valid && jj == 0 && a.sweep_counts) a.sweep_counts[b] = stats.sweeps;
       wave_sync();
     }
     if (valid && jj == 0) a.cost[b] = obj_out;

@@ -693,7 +693,7 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
 // J decreases strictly from iterate to iterate, so no face is visited twice.
 // ---------------------------------------------------------------------------------------------
 struct QpStats {   // per row, counted by the caller
-  int newton = 0, arcs = 0;
+  int sweeps = 0, ratio_steps = 0;                   // pinned Riccati sweeps, ratio-test steps
   int end_kkt = 0, end_precision = 0, end_cap = 0;   // how the solve ended
 };
 
@@ -766,12 +766,12 @@ __device__ __forceinline__ double rollout_policy(const Prov& prov, int T, S x0, 
   return rowsum<NX>(cx) + cu;
 }
 
-// open-loop rollout of u = clip(u^k + alpha (u_N - u^k)) with the objective of optimize.py:33-34,54; writes (Xc, Uc).
+// open-loop rollout of u = clip(U) (the starting point of a solve) with the objective of optimize.py:33-34,54;
+// writes the clipped controls and their trajectory to (Xc, Uc).
 template <class S, int NX, int NU, class Prov>
-__device__ __forceinline__ double rollout_arc(const Prov& prov, int T, S x0, const Window& win, const CostRef<S>& cost,
-                                              const GView& Uk, const GView& Un, double alpha, const Box& box,
-                                              const double (&lo0)[NU], const double (&hi0)[NU], const GView& Xc, const GView& Uc,
-                                              int j, bool store_ok) {
+__device__ __forceinline__ double rollout_open(const Prov& prov, int T, S x0, const Window& win, const CostRef<S>& cost,
+                                               const GView& U, const Box& box, const double (&lo0)[NU], const double (&hi0)[NU],
+                                               const GView& Xc, const GView& Uc, int j, bool store_ok) {
   S x = x0;
   if (store_ok) Xc.st<S>(j, x);
   double cx = 0.0, cu = 0.0;
@@ -787,10 +787,9 @@ __device__ __forceinline__ double rollout_arc(const Prov& prov, int T, S x0, con
     S xn = cadd(ax, dlt);
 #pragma unroll
     for (int k = 0; k < NU; ++k) {
-      const double uk = Uk.ld<double>(t * NU + k), un = Un.ld<double>(t * NU + k);
       double lo, hi;
       box.at<NU>(t, k, lo0, hi0, lo, hi);
-      u[k] = fmin(fmax(fma(alpha, un - uk, uk), lo), hi);
+      u[k] = fmin(fmax(U.ld<double>(t * NU + k), lo), hi);
       eu[k] = u[k] - win.ubm.ld<double>(t * NU + k);
       cmac_r(xn, Brow[k], u[k]);
     }
@@ -868,7 +867,7 @@ __device__ __forceinline__ bool box_qp_iterate(const Prov& prov, int T, S x0, co
     RolloutInfo ri;
     const double Jc = rollout_policy<S, NX, NU>(prov, T, x0, win, cost, gains, pin, Uk, true, Xc, Uc, j, going && lane_ok, ri);
     wave_sync();
-    if (going) ++r.stats.newton;
+    if (going) ++r.stats.sweeps;
     bool moved = false;
     if (going && !(ri.dmax > 1e-13 * box.sat)) {
       // the policy reproduces the iterate: it is the minimiser of its face (or NaN)
@@ -894,7 +893,7 @@ __device__ __forceinline__ bool box_qp_iterate(const Prov& prov, int T, S x0, co
       const double Jn = rollout_policy<S, NX, NU>(prov, T, x0, win, cost, gains, pin, Uk, false, Xc, Uc, j, ratio && lane_ok, rn);
       wave_sync();
       if (ratio) {
-        ++r.stats.arcs;
+        ++r.stats.ratio_steps;
         const double al = rn.alpha;
         // blend in place: trial = iterate + al (Newton - iterate); blocking controls land exactly on their bound
         if (lane_ok) {
