@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="collective backend for N > 1: nccl (= RCCL over xGMI, the real thing) or "
                                                       "gloo (rehearsal on a box with fewer GPUs than ranks: results staged through the host)")
+    ap.add_argument("--exact-qp", action="store_true", help="not the headline: every QP solved to the box-constrained optimum "
+                                                            "(M4Q_QP_EXACT_BOX); roofline flops then count pinned sweeps")
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: take the N > 1 code path (process group, torch-owned "
                                                               "output buffers, gather) even with one rank")
     args = ap.parse_args()
@@ -106,7 +108,7 @@ def main():
     per_model = p["scales"] is not None
 
     sess = EnsembleSession(B, n, m, p["order"], T, ns, p["dt"], p["sat"], p["du"], model_per_instance=per_model,
-                           target_cols=ns + T + 1, device=dev_index if multi else -1)
+                           target_cols=ns + T + 1, device=dev_index if multi else -1, exact_qp=args.exact_qp)
     gather_bufs = None
     if multi:
         # results live in torch-owned HBM so RCCL can gather them without a copy
@@ -181,6 +183,10 @@ def main():
         value = units_total * args.steps / elapsed
         avg_launch_s = kern_ms / max(launches, 1) / 1e3
         flops = ALG_FLOP[n] * units_per_step
+        qp_stats = sess.qp_stats() if args.exact_qp else None
+        if qp_stats:
+            # one pinned sweep + policy rollout over the horizon is the arithmetic of one clipped solve
+            flops = ALG_FLOP[n] * T * qp_stats[1]
         abytes = alg_bytes_per_hstep(n, m, P, T) * units_per_step
         traffic = None
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -199,10 +205,14 @@ def main():
                                    "per-instance models, full closed loop per step; %s arithmetic path" % (args.config, p["d"], n, m, p["order"], T, ns, B, path),
                        "batch_per_gpu": B, "horizon": T, "n_steps": ns, "qp_solves_per_step": units_per_step // T,
                        "instances_ok": ok_total, "parallelism": "ensemble-sharded x%d, one gather" % world,
-                       "grid": info["grid"], "lds_bytes": info["lds_bytes"], "hbm_resident_bytes": info["hbm_bytes"]},
+                       "grid": info["grid"], "lds_bytes": info["lds_bytes"], "hbm_resident_bytes": info["hbm_bytes"],
+                       **({"qp_mode": "exact box-constrained (active set on the Riccati factorisation)",
+                           "exact_qp_stats": dict(zip(("qp_solves", "pinned_sweeps", "ratio_steps", "end_kkt", "end_precision",
+                                                       "end_cap"), qp_stats))} if qp_stats else {})},
             "roofline": {"bound": "mfma", "achieved": flops / avg_launch_s / 1e12, "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s",
                          "frac": flops / avg_launch_s / 1e12 / PEAK_F64_TFLOPS, "traffic": traffic,
-                         "kernel": "mpc_kernel<%s, PLANT_HAMILTONIAN>" % ("double" if path == "real" else "cplx"), "launches": launches, "avg_launch_ms": 1e3 * avg_launch_s,
+                         "kernel": "mpc_kernel<%s, PLANT_HAMILTONIAN, %s>" % ("double" if path == "real" else "cplx",
+                                                                              "true" if args.exact_qp else "false"), "launches": launches, "avg_launch_ms": 1e3 * avg_launch_s,
                          "note": "fp64 compute roof: v_fma_f64 (VALU, used here with DPP row broadcasts) and v_mfma_f64 share the "
                                  "78.6 TFLOP/s dense rate on MI355X; achieved = ALGORITHMIC flops (SURVEY 8d, complex recursion) / launch time. "
                                  "The real path executes a quarter of them: its executed-FMA issue rate is 47% of peak, the complex path's 72% "
