@@ -6,7 +6,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import mpc4quantum_amd as m4q            # noqa: E402
 from mpc4quantum_amd import configs      # noqa: E402
 from oracle import m4q_oracle as orc     # noqa: E402

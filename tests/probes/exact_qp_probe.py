@@ -6,7 +6,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ.setdefault("M4Q_QP_TRACE", "1")
 import mpc4quantum_amd as m4q            # noqa: E402
 from mpc4quantum_amd import configs      # noqa: E402
