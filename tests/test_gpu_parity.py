@@ -580,9 +580,11 @@ def test_closed_loop_lqr_mode_vs_oracle():
     assert rel(res["us"], us) <= 1e-5 and rel(res["xs"], xs) <= 1e-5
 
 
-def test_mpc_dropin_fused_equals_host_plant_and_oracle():
+@pytest.mark.parametrize("exact", [False, True])
+def test_mpc_dropin_fused_equals_host_plant_and_oracle(exact):
     """mpc() with this package's QExperiment (fused, one launch) == mpc() with a foreign experiment object
-    (one launch per step, plant on the host) == oracle; return shapes and clock mutation as mpc.py:294-304."""
+    (one launch per step, plant on the host) == oracle; return shapes and clock mutation as mpc.py:294-304.
+    exact: the QPs solved to the box-constrained optimum (exact_qp=True) against the oracle's BVLS loop."""
     p = configs.build(3, batch=1, horizon=12, n_steps=8)
     n, m = p["dim_x"], p["dim_u"]
     model = m4q.DMDc(n, n, p["models"].shape[2] - n, p["models"][0])
@@ -590,7 +592,7 @@ def test_mpc_dropin_fused_equals_host_plant_and_oracle():
     def run(exp, **kw):
         clock = m4q.StepClock(p["dt"], p["horizon"], p["n_steps"])
         out = m4q.mpc(p["x0"][0], m, p["order"], p["X_targ"], p["U_targ"], clock, exp, model, p["Q"], p["R"], p["Qf"],
-                      sat=p["sat"], du=p["du"], progress_bar=False, **kw)
+                      sat=p["sat"], du=p["du"], progress_bar=False, exact_qp=exact, **kw)
         return out, clock
     (d1, _, c1), clk1 = run(m4q.QExperiment(p["plant_op0"][0], list(p["plant_ops"][0])))
     (d2, _, c2), clk2 = run(orc.OracleQExperiment(p["plant_op0"][0], list(p["plant_ops"][0])))
@@ -598,7 +600,7 @@ def test_mpc_dropin_fused_equals_host_plant_and_oracle():
     (xo, uo), _, co = orc.mpc(p["x0"][0], m, p["order"], p["X_targ"], p["U_targ"], oclk,
                               orc.OracleQExperiment(p["plant_op0"][0], list(p["plant_ops"][0])),
                               orc.OracleDMDc(n, n, p["models"].shape[2] - n, p["models"][0]), p["Q"], p["R"], p["Qf"],
-                              sat=p["sat"], du=p["du"])
+                              sat=p["sat"], du=p["du"], qp_mode="exact" if exact else "qp")
     assert c1 == c2 == co == 0
     assert d1[0].shape == (n, 9) and d1[1].shape == (m, 8)
     assert len(clk1.ts_sim) == len(clk2.ts_sim) == len(oclk.ts_sim) == 8
