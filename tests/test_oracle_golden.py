@@ -141,3 +141,38 @@ def test_clipped_riccati_vs_exact_box_qp():
             assert np.abs(Uc - Ue).max() < 1e-8 and abs(cc - ce) < 1e-8 * max(1, ce)
         else:
             assert np.isclose(np.abs(Ue).max(), sat) and cc >= ce - 1e-9 and np.abs(Uc - Ue).max() > 1e-3
+
+
+def test_exact_box_qp_oracle_satisfies_kkt():
+    """The BVLS reference solution of the box-constrained QP (optimize.py:27-54) satisfies the KKT conditions of that
+    statement, evaluated independently through the adjoint recursion: zero gradient on interior controls, gradient
+    pushing outward on controls at a bound.  Pins `exact_quad_program`, the checker of the device's exact mode."""
+    from mpc4quantum_amd import configs
+    p = configs.build(3, batch=1, order=2, horizon=12)
+    n, m, T = 9, 2, 12
+    mdl = p["models"][0]
+    wm = orc.OracleWrapModel(mdl[:, :n], mdl[:, n:], m, 2)
+    rng = np.random.default_rng(11)
+    Xg = np.tile(p["x0"][0][:, None], (1, T + 1))
+    Ug = 0.3 * p["sat"] * rng.uniform(-1, 1, (m, T))
+    A_ls, B_ls, D_ls = wm.get_model_along_traj(Xg, Ug, np.arange(T))
+    X_bm, U_bm = p["X_targ"][:, :T + 1], p["U_targ"][:, :T].real
+    Q_ls, R_ls = [p["Q"]] * T + [p["Qf"]], [p["R"]] * T
+    sat, du = p["sat"], 0.2 * p["sat"]
+    u_prev = np.array([0.05, -0.02])
+    Q_ls = [0.02 * q for q in Q_ls]                      # softer tracking: a mix of interior and saturated controls
+    X, U, cost = orc.exact_quad_program(Xg[:, 0], X_bm, U_bm, Q_ls, R_ls, A_ls, B_ls, D_ls, u_prev, sat, du)
+    lo, hi = -sat * np.ones((m, T)), sat * np.ones((m, T))
+    lo[:, 0], hi[:, 0] = np.maximum(lo[:, 0], u_prev - du), np.minimum(hi[:, 0], u_prev + du)
+    assert np.all(U >= lo - 1e-12) and np.all(U <= hi + 1e-12)
+    lam = Q_ls[T] @ (X[:, T] - X_bm[:, T])
+    g = np.zeros((m, T))
+    for t in range(T - 1, -1, -1):
+        g[:, t] = 2 * np.real(R_ls[t] @ (U[:, t] - U_bm[:, t]) + B_ls[t].conj().T @ lam)
+        lam = Q_ls[t] @ (X[:, t] - X_bm[:, t]) + A_ls[t].conj().T @ lam
+    at_lo, at_hi = U <= lo + 1e-10, U >= hi - 1e-10
+    interior = ~(at_lo | at_hi)
+    scale = np.abs(g).max()
+    assert at_lo.sum() + at_hi.sum() > 3 and interior.sum() > 3
+    assert np.abs(g[interior]).max() <= 1e-8 * scale
+    assert np.all(g[at_lo] >= -1e-8 * scale) and np.all(g[at_hi] <= 1e-8 * scale)
