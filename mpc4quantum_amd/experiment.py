@@ -119,6 +119,14 @@ class LExperiment(QExperiment):
         return self.xs
 
 
+def split_blocks(bmatrix, nrows, ncols):
+    """experiment.py:309-315: the (nrows x ncols) tiles of a block matrix, row-major over the tiles."""
+    bmatrix = np.asarray(bmatrix)
+    tiles_down, tiles_across = bmatrix.shape[0] // nrows, bmatrix.shape[1] // ncols
+    return np.stack([bmatrix[a * nrows:(a + 1) * nrows, b * ncols:(b + 1) * ncols]
+                     for a in range(tiles_down) for b in range(tiles_across)])
+
+
 def isqrt(n):
     """Integer square root (experiment.py:311-327)."""
     import math

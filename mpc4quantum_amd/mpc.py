@@ -52,8 +52,30 @@ def shift_guess(data):
     return np.hstack([data[:, 1:], data[:, -1:]])
 
 
+def isinf_warning():
+    """mpc.py:76-79: what the reference prints on exit code 3."""
+    import warnings
+    warnings.warn("Solution was infinite (failed to converge). Inspect the model for accuracy, check if control constraints "
+                  "can regularize the problem, or run with verbose=True for more information.")
+
+
 def complex_to_real(z):
+    """mpc.py:87-89: complex vector of length n -> [Re; Im] of length 2n."""
     return np.concatenate((np.real(z), np.imag(z)))
+
+
+def real_to_complex(z):
+    """mpc.py:82-84: the inverse, [Re; Im] -> complex."""
+    z = np.asarray(z)
+    half = len(z) // 2
+    return z[:half] + 1j * z[half:]
+
+
+def real_to_complex_op(P):
+    """mpc.py:96-98: inverse of complex_to_real_op, read off the left block column."""
+    P = np.asarray(P)
+    r, c = P.shape[0] // 2, P.shape[1] // 2
+    return P[:r, :c] + 1j * P[r:, :c]
 
 
 def complex_to_real_op(P):

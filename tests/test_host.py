@@ -135,6 +135,17 @@ def test_partial_trace_lift_proj_known_answer():
     l2 = m4q.QExperiment32.lift(r3.flatten())
     assert l2.shape == (4,) and abs(l2[0] + l2[3] - 1) < 1e-14
     assert np.allclose(l2.reshape(2, 2), r3[:2, :2] / np.trace(r3[:2, :2]))
+    # mpc.py:82-98 real/complex packing helpers and experiment.py:309-315 split_blocks
+    z = np.array([1 + 2j, 3 - 1j, -0.5j])
+    assert np.array_equal(m4q.real_to_complex(m4q.complex_to_real(z)), z)
+    P = np.arange(9).reshape(3, 3) * (1 - 0.5j) + np.eye(3) * 2j
+    assert np.array_equal(m4q.real_to_complex_op(m4q.complex_to_real_op(P)), P)
+    assert np.allclose(m4q.complex_to_real_op(P) @ m4q.complex_to_real(z), m4q.complex_to_real(P @ z))
+    blocks = m4q.split_blocks(np.arange(24).reshape(4, 6), 2, 3)
+    assert blocks.shape == (4, 2, 3)
+    assert np.array_equal(blocks[1], [[3, 4, 5], [9, 10, 11]]) and np.array_equal(blocks[2], [[12, 13, 14], [18, 19, 20]])
+    with pytest.warns(UserWarning):
+        m4q.isinf_warning()
     assert m4q.isqrt(16) == 4 and m4q.isqrt(17) == 4 and m4q.isqrt(0) == 0
     with pytest.raises(ValueError):
         m4q.isqrt(-1)
