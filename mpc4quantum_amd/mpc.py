@@ -147,6 +147,8 @@ def mpc(x0, dim_u, order, X_targ, U_targ, clock, experiment, model, Q, R, Qf, sa
             sess.run(0, ns)
             res = sess.results()
             code, done = int(res["exit_codes"][0]), int(res["steps_done"][0])
+            if code == 3:
+                isinf_warning()                                                                # mpc.py:200-203
             clock.set_endsim(done if code else done)
             return _trim(res["xs"][0].T, res["us"][0].T, code, done), model, code
         # host plant: one launch per MPC step, the plant (and lift/proj) evaluated by the caller's object
@@ -167,6 +169,8 @@ def mpc(x0, dim_u, order, X_targ, U_targ, clock, experiment, model, Q, R, Qf, sa
             dev_code = int(sess.download(_lib.F_CODES, (1,))[0])
             if dev_code:
                 code = dev_code
+                if code == 3:
+                    isinf_warning()
                 break
             u = sess.download(_lib.F_US, (1, ns, dim_u))[0, step]
             us.append(u)
