@@ -690,6 +690,36 @@ def test_closed_loop_generator_plant_with_dissipation():
     assert abs(res["xs"][0, 0, -1] + res["xs"][0, 3, -1] - 1) < 1e-10        # trace preserved by the Lindbladian
 
 
+@pytest.mark.parametrize("kw", [{}, {"force_complex": True}, {"exact_qp": True}])
+def test_closed_loop_qubit_with_two_quadrature_drives(kw):
+    """Shape (4, 2, 1): a detuned qubit driven on both quadratures (sigma_x and sigma_y), the common single-qubit setup
+    beyond the reference's one-control tests; model built by discretize_homogeneous from the Liouvillians."""
+    from mpc4quantum_amd.configs import SX, SY, SZ, rx
+    dt, T, ns = 0.5, 12, 10
+    H0, Hk = 0.15 * SZ, [0.5 * SX, 0.5 * SY]
+    model = m4q.discretize_homogeneous([m4q.liouvillian(H0)] + [m4q.liouvillian(h) for h in Hk], dt, 1)[None]
+    sat = 2 * np.pi * 0.08
+    r0 = rx(0.3)
+    rho0 = (r0 @ np.diag([1.0, 0]).astype(complex) @ r0.conj().T).reshape(1, 4)
+    x0 = np.concatenate([rho0, np.diag([1.0, 0]).astype(complex).reshape(1, 4)])
+    target = np.array([0.5, -0.5j, 0.5j, 0.5])                    # |+i><+i|: needs both quadratures
+    X_t = np.tile(target[:, None], (1, ns + T + 1))
+    U_t = np.zeros((2, ns + T))
+    Q = np.eye(4)
+    R = 1e-2 / sat ** 2 * np.eye(2)
+    clock = m4q.StepClock(dt, T, ns)
+    res = m4q.mpc_batch(x0, model, 2, 1, X_t, U_t, clock, H0[None], np.stack(Hk)[None], Q, R, Q, sat, 0.5 * sat, **kw)
+    xs, us, codes, solves = orc.mpc_batch(x0, model, 2, 1, X_t, U_t, dt, T, ns, H0[None], Hk, Q, R, Q, sat, 0.5 * sat,
+                                          qp_mode="exact" if kw.get("exact_qp") else "qp")
+    assert res["path"] == ("complex" if kw.get("force_complex") else "real")
+    assert np.array_equal(res["exit_codes"], codes) and np.array_equal(res["qp_solves"], solves)
+    assert rel(res["us"][:, :, :2], us[:, :, :2]) <= 1e-9 and rel(res["xs"][:, :, :3], xs[:, :, :3]) <= 1e-9
+    assert rel(res["us"], us) <= 1e-5 and rel(res["xs"], xs) <= 1e-5
+    assert np.abs(us[:, 1, :]).max() > 0.1 * sat                  # the sigma_y drive is really used
+    fid = np.real(np.einsum("i,bi->b", target.conj(), res["xs"][:, :, -1]))
+    assert np.all(fid > 0.9)                                       # and the loop gets there
+
+
 def test_closed_loop_long_horizon_config5_shape():
     """BASELINE config 5's shape (T = 80) on two members, and the degenerate n_steps = 1 / T = 2 corner."""
     p = configs.build(5, batch=2, n_steps=4)

@@ -182,7 +182,7 @@ def test_problem_struct_layout_matches_header():
 
 def test_supported_shapes():
     assert _lib.supported(4, 1, 1) and _lib.supported(9, 2, 1) and _lib.supported(9, 2, 2) and _lib.supported(16, 3, 1)
-    assert _lib.supported(8, 2, 1) and not _lib.supported(25, 1, 1)
+    assert _lib.supported(8, 2, 1) and _lib.supported(4, 2, 1) and not _lib.supported(25, 1, 1)
 
 
 def test_fails_loudly_without_a_gpu():
