@@ -7,7 +7,7 @@ from .experiment import (Experiment, LExperiment, QCoupledExperiment, QExperimen
 from .library import (create_library, create_library_from_list, create_power_list, diff_library, krtimes,  # noqa: F401
                       multinomial_powers, size_of_library)
 from .linearize import WrapModel  # noqa: F401
-from .model import DMDc  # noqa: F401
+from .model import DMDc, DiscrepDMDc, OnlineDMDc  # noqa: F401
 from .mpc import (StepClock, complex_to_real, complex_to_real_op, iqp_line_search, isinf_warning, mpc, mpc_batch,  # noqa: F401
                   real_to_complex, real_to_complex_op, shift_guess, val_to_str)
 from .optimize import quad_program, quad_program_batch  # noqa: F401

@@ -575,7 +575,7 @@ class OracleQCoupledExperiment(OracleQExperiment):
 
 
 def mpc(x0, dim_u, order, X_targ, U_targ, clock, experiment, model, Q, R, Qf, sat=None, du=None, max_iter=100,
-        exit_condition=None, warm_start=True, qp_mode="qp", count=None, trace=None):
+        exit_condition=None, warm_start=True, qp_mode="qp", count=None, trace=None, streaming=False):
     """Receding-horizon loop restating mpc.py:128-304 for streaming == False (any clock.measure_freq),
     with ``quad_program`` being the Riccati solver above (qp_mode "qp"), the lqr.py restatement
     (qp_mode "lqr") or the exact box-constrained solve (qp_mode "exact", BVLS).  Keeps the quirks: u_prev from
@@ -646,6 +646,12 @@ def mpc(x0, dim_u, order, X_targ, U_targ, clock, experiment, model, Q, R, Qf, sa
         U_guess = shift_guess(U_guess)
         X_ref = np.atleast_2d(X_targ[:, step:step + T + 1])
         U_ref = np.atleast_2d(U_targ[:, step:step + T])
+        if streaming:
+            # mpc.py:281-285: the model object is refitted with this step's transition; the loop keeps linearising the
+            # operators it extracted at entry (quirk Q6)
+            lx = np.reshape(experiment.lift(xs[step]), (-1, 1))
+            model.fit_iteration(np.reshape(experiment.lift(xs[step + 1]), (-1, 1)), lx,
+                                krtimes(wm.lift_u(us[step].reshape(-1, 1)), lx))
         if exit_condition is not None and exit_condition(xs[step + 1], xs[step], us[step]):
             exit_code = 1
             break

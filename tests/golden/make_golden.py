@@ -2,6 +2,7 @@
 
 Run once in the build container (where /root/reference exists):
     python tests/golden/make_golden.py
+(`python tests/golden/make_golden.py dmdc` regenerates only dmdc.npz.)
 The reference modules are loaded by file path (the package __init__ needs qutip/cvxpy, which are
 absent); only linearize.py, lqr.py, model.py and vectorize.py are executed.  Two harness-side
 shims restore NumPy-1 names the reference uses (np.product, np.math); an inert module named
@@ -155,5 +156,53 @@ def main():
     print("wrote", sorted(f for f in os.listdir(OUT) if f.endswith(".npz")))
 
 
+def golden_dmdc():
+    """(5) the streaming model refits of model.py:109-313 (DiscrepDMDc, OnlineDMDc) on seeded complex snapshot data:
+    batch fits, then the model after each of a run of fit_iteration updates."""
+    mdl = load_reference()["model"]
+    rng = np.random.default_rng(20211014)
+    n, k, N, steps = 4, 4, 24, 8
+
+    def cplx(*shape):
+        return rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+    A_true = 0.4 * cplx(n, n + k)
+    X, U = cplx(n, N), cplx(k, N)
+    Y = A_true @ np.vstack([X, U]) + 1e-3 * cplx(n, N)
+    Xs, Us = cplx(n, steps), cplx(k, steps)
+    Ys = A_true @ np.vstack([Xs, Us]) + 1e-3 * cplx(n, steps)
+    A_boot = A_true + 0.05 * cplx(n, n + k)
+    out = dict(X=X, U=U, Y=Y, Xs=Xs, Us=Us, Ys=Ys, A_boot=A_boot)
+
+    d = mdl.DiscrepDMDc.from_data(Y, X, U, rcond=1e-12)
+    out["discrep_from_data_A"] = d.A
+    d = mdl.DiscrepDMDc.from_bootstrap(n, n, k, A_boot.copy())
+    d.discount = 0.9
+    d.append(Y[:, :6], X[:, :6], U[:, :6])
+    seq = []
+    for i in range(steps):
+        A_x, A_u = d.fit_iteration(Ys[:, i], Xs[:, i], Us[:, i])
+        seq.append(np.hstack([A_x, A_u]))
+    out["discrep_stream_A"] = np.stack(seq)
+    out["discrep_stream_Y"] = d.Y
+
+    o = mdl.OnlineDMDc.from_data(Y, X, U)
+    out["online_from_data_A"], out["online_from_data_P"] = o.A, o.P
+    o = mdl.OnlineDMDc.from_bootstrap(n, n, k, A_boot.copy(), alpha=1e2)
+    o.discount = 0.95
+    seqA, seqP = [], []
+    for i in range(steps):
+        o.fit_iteration(Ys[:, i], Xs[:, i], Us[:, i])
+        seqA.append(o.A.copy())
+        seqP.append(o.P.copy())
+    out["online_stream_A"], out["online_stream_P"] = np.stack(seqA), np.stack(seqP)
+    out["predict"] = o.predict(Xs, Us)
+    np.savez(os.path.join(OUT, "dmdc.npz"), **out)
+    print("wrote dmdc.npz")
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["dmdc"]:
+        golden_dmdc()
+    else:
+        main()
+        golden_dmdc()

@@ -608,6 +608,31 @@ def test_mpc_dropin_fused_equals_host_plant_and_oracle(exact):
     assert rel(d2[0], xo) <= 1e-8 and rel(d2[1], uo) <= 1e-8
 
 
+def test_mpc_streaming_refits_the_model_object():
+    """streaming=True (mpc.py:281-285): after every MPC step the model object is refitted with the measured transition
+    (here OnlineDMDc, recursive least squares), while the loop keeps the operators extracted at entry (quirk Q6): the
+    controls equal the non-streaming run, the returned model has moved towards the plant."""
+    p = configs.build(1, batch=1)
+    A0 = p["models"][0]
+
+    def run(mod, clock_cls, exp, model, **kw):
+        clock = clock_cls(p["dt"], p["horizon"], p["n_steps"])
+        return mod(p["x0"][0], 1, 1, p["X_targ"], p["U_targ"], clock, exp, model, p["Q"], p["R"], p["Qf"], sat=p["sat"],
+                   du=p["du"], streaming=True, **kw)
+    exp = m4q.QExperiment(p["plant_op0"][0], list(p["plant_ops"][0]))
+    (xs, us), mdl, code = run(m4q.mpc, m4q.StepClock, exp, m4q.OnlineDMDc.from_bootstrap(4, 4, 4, A0.copy(), alpha=1e-2),
+                              progress_bar=False)
+    oexp = orc.OracleQExperiment(p["plant_op0"][0], list(p["plant_ops"][0]))
+    (xo, uo), omdl, co = run(orc.mpc, orc.OracleClock, oexp, m4q.OnlineDMDc.from_bootstrap(4, 4, 4, A0.copy(), alpha=1e-2))
+    assert code == co == 0 and mdl._iteration == omdl._iteration == p["n_steps"]
+    assert rel(us, uo) <= 1e-8 and rel(xs, xo) <= 1e-8
+    assert rel(mdl.A, omdl.A) <= 1e-8 and np.abs(mdl.A - A0).max() > 1e-6          # refitted, identically
+    clock = m4q.StepClock(p["dt"], p["horizon"], p["n_steps"])
+    (x2, u2), _, _ = m4q.mpc(p["x0"][0], 1, 1, p["X_targ"], p["U_targ"], clock, exp, m4q.DMDc(4, 4, 4, A0), p["Q"], p["R"], p["Qf"],
+                             sat=p["sat"], du=p["du"], progress_bar=False)
+    assert rel(us, u2) <= 1e-8                                                    # Q6: the refit does not steer the loop
+
+
 def test_mpc_exit_condition_and_exit_code_1():
     p = configs.build(1, batch=1)
     model = m4q.DMDc(4, 4, 4, p["models"][0])

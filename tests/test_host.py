@@ -198,3 +198,42 @@ def test_fails_loudly_without_a_gpu():
         m4q.plant_step_batch(np.zeros((1, 4)), np.zeros((1, 1)), np.eye(2), np.eye(2)[None], 0.1)
     with pytest.raises(TypeError):
         m4q.EnsembleSession(4, 4, 1, 1, 5, 3, 1.0, None)
+
+
+def test_streaming_dmdc_refits_vs_reference_golden(golden):
+    """DiscrepDMDc / OnlineDMDc (model.py:109-313), the models mpc(..., streaming=True) refits through fit_iteration:
+    batch fits and the model after each of eight streaming updates against the reference's own classes."""
+    g = golden("dmdc")
+    X, U, Y, Xs, Us, Ys, A_boot = (g[k] for k in ("X", "U", "Y", "Xs", "Us", "Ys", "A_boot"))
+    n, k = X.shape[0], U.shape[0]
+
+    def close(a, b):
+        return np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max())
+    d = m4q.DiscrepDMDc.from_data(Y, X, U, rcond=1e-12)
+    assert (d.dim_y, d.dim_x, d.dim_u) == (n, n, k) and close(d.A, g["discrep_from_data_A"])
+    d = m4q.DiscrepDMDc.from_bootstrap(n, n, k, A_boot.copy())
+    d.discount = 0.9
+    d.append(Y[:, :6], X[:, :6], U[:, :6])
+    for i in range(Xs.shape[1]):
+        A_x, A_u = d.fit_iteration(Ys[:, i], Xs[:, i], Us[:, i])
+        assert close(np.hstack([A_x, A_u]), g["discrep_stream_A"][i])
+    assert close(d.Y, g["discrep_stream_Y"])
+    o = m4q.OnlineDMDc.from_data(Y, X, U)
+    assert close(o.A, g["online_from_data_A"]) and close(o.P, g["online_from_data_P"])
+    o = m4q.OnlineDMDc.from_bootstrap(n, n, k, A_boot.copy(), alpha=1e2)
+    o.discount = 0.95
+    for i in range(Xs.shape[1]):
+        o.fit_iteration(Ys[:, i], Xs[:, i], Us[:, i])
+        assert close(o.A, g["online_stream_A"][i]) and close(o.P, g["online_stream_P"][i])
+    assert close(o.predict(Xs, Us), g["predict"])
+    # the refit pulls the bootstrapped model towards the data
+    A_true_fit = g["discrep_from_data_A"]
+    assert np.abs(o.A - A_true_fit).max() < 0.5 * np.abs(A_boot - A_true_fit).max()
+    # saved history and the no-control form
+    o._save, o._isave = True, 1
+    o.fit_iteration(Ys[:, 0], Xs[:, 0], Us[:, 0])
+    assert len(o.iA) == 2 and len(o.iP) == 2
+    d0 = m4q.DiscrepDMDc.from_data(Y, X, None, rcond=1e-12)
+    assert d0.dim_u == 0 and d0.A.shape == (n, n)
+    with pytest.raises(NotImplementedError):
+        m4q.DMDc(n, n, k, A_boot).fit_iteration(Ys[:, 0], Xs[:, 0], Us[:, 0])
