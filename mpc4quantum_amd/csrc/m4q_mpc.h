@@ -94,6 +94,16 @@ struct Poly {
   }
 };
 
+// order 1: the library after the constant is u_1 .. u_m in this order (linearize.py:113-116)
+template <int NU>
+constexpr bool order1_is_identity() {
+  constexpr PowTab<NU, 1> tab{};
+  for (int p = 0; p < NU; ++p)
+    for (int k = 0; k < NU; ++k)
+      if (tab.e[p + 1][k] != (p == k ? 1 : 0)) return false;
+  return true;
+}
+
 template <int NX>
 struct ModelPitch {
   // Row pitch (in elements) of a model block in LDS.  Both access patterns must stay off a single bank:
@@ -236,8 +246,13 @@ struct FusedProv {
 #pragma unroll
     for (int k = 0; k < NU; ++k) {
       S b = zero_of<S>();
+      if constexpr (ORDER == 1) {
+        static_assert(ORDER != 1 || order1_is_identity<NU>(), "order-1 library must list u_1 .. u_m in order");
+        b = nx[k];                           // monomial p is u_p: d(mono_p)/du_k = delta_pk
+      } else {
 #pragma unroll
-      for (int p = 0; p < NP; ++p) cmac_r(b, nx[p], po.dpu[k][p]);
+        for (int p = 0; p < NP; ++p) cmac_r(b, nx[p], po.dpu[k][p]);
+      }
       Brow[k] = b;
       cmac_r(dlt, b, -l.u[k]);
     }
