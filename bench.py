@@ -34,34 +34,64 @@ def alg_bytes_per_hstep(n, m, P, T):
     return (16 * n * n * (1 + P) + 16 * n * (T + 1) + 8 * m * T + 16 * n * (T + 1) + 8 * m * T) / T
 
 
-def cpu_baseline(p, seconds_budget=20.0):
-    """The NumPy oracle (a port of the reference arithmetic) on one host core, on the first members
-    of the same ensemble until ~seconds_budget is spent."""
+def _cpu_worker(config, lo, hi, budget):
+    """One host core: the NumPy oracle (a port of the reference arithmetic) on members [lo, hi) of the ensemble, member by
+    member, until the time budget is spent.  Runs in its own process (`bench.py --cpu-worker`), which never touches the GPU."""
+    from mpc4quantum_amd import configs
     from oracle import m4q_oracle as orc
-    import numpy as np
-    units = 0
-    done = 0
+    q = configs.build(config, batch=hi - lo, offset=lo, total=max(hi, {1: 1, 2: 8192, 3: 65536, 4: 65536, 5: 2 ** 20}[config]),
+                      host_models=False)
+    units = done = 0
     spent = 0.0
-    while done < p["x0"].shape[0] and (spent < seconds_budget or done < 2):
-        if p["scales"] is not None:      # the member's model, built outside the timed part (setup, not the hot path)
-            gens = [p["scales"][done, k] * p["generators"][k] for k in range(p["generators"].shape[0])]
-            mdl = orc.discretize_homogeneous(gens, p["dt"], p["order"])[None]
+    while done < hi - lo and (spent < budget or done < 1):
+        if q["scales"] is not None:      # the member's model, built outside the timed part (setup, not the hot path)
+            gens = [q["scales"][done, k] * q["generators"][k] for k in range(q["generators"].shape[0])]
         else:
-            mdl = orc.discretize_homogeneous(list(p["generators"]), p["dt"], p["order"])[None]
+            gens = list(q["generators"])
+        mdl = orc.discretize_homogeneous(gens, q["dt"], q["order"])[None]
         t0 = time.perf_counter()
-        _, _, _, solves = orc.mpc_batch(p["x0"][done:done + 1], mdl, p["dim_u"], p["order"], p["X_targ"], p["U_targ"], p["dt"],
-                                        p["horizon"], p["n_steps"], p["plant_op0"], list(p["plant_ops"][0]), p["Q"], p["R"],
-                                        p["Qf"], p["sat"], p["du"])
+        _, _, _, solves = orc.mpc_batch(q["x0"][done:done + 1], mdl, q["dim_u"], q["order"], q["X_targ"], q["U_targ"], q["dt"],
+                                        q["horizon"], q["n_steps"], q["plant_op0"], list(q["plant_ops"][0]), q["Q"], q["R"],
+                                        q["Qf"], q["sat"], q["du"])
         spent += time.perf_counter() - t0
-        units += int(solves.sum()) * p["horizon"]
+        units += int(solves.sum()) * q["horizon"]
         done += 1
-    dt = spent
-    return {"value": units / dt, "unit": "MPC horizon-steps/s", "cores": 1, "kind": "port",
-            "sample": "first %d of %d ensemble members, full closed loop (n_steps=%d, T=%d), NumPy oracle, %.1f s"
-                      % (done, p["x0"].shape[0], p["n_steps"], p["horizon"], dt)}
+    print(json.dumps({"units": units, "members": done, "seconds": spent}))
+
+
+def cpu_baseline(config, p, cores, seconds_budget=20.0, members_per_core=64):
+    """The oracle on `cores` host cores: one single-threaded child process each (`bench.py --cpu-worker ...`), each on its
+    own slice of the first members of the same ensemble for ~seconds_budget.  Rate = all horizon-steps / longest worker."""
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = []
+    for c in range(cores):
+        lo, hi = c * members_per_core, min((c + 1) * members_per_core, p["x0"].shape[0])
+        if lo >= hi:
+            break
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(config), str(lo), str(hi),
+                                       str(seconds_budget)], stdout=subprocess.PIPE, env=env, cwd=ROOT))
+    results = []
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=seconds_budget * 6 + 120)
+            results.append(json.loads(out.decode().strip().splitlines()[-1]))
+        except Exception:                                # a worker that died or hung is left out of the sum
+            pr.kill()
+    if not results:
+        return None
+    units = sum(r["units"] for r in results)
+    wall = max(r["seconds"] for r in results)
+    return {"value": units / wall, "unit": "MPC horizon-steps/s", "cores": len(results), "kind": "port",
+            "per_core": units / sum(r["seconds"] for r in results),
+            "sample": "%d of %d ensemble members (%d processes x ~%.0f s, one core each), full closed loop (n_steps=%d, T=%d), "
+                      "NumPy oracle" % (sum(r["members"] for r in results), p["x0"].shape[0], len(results), wall, p["n_steps"],
+                                        p["horizon"])}
 
 
 def main():
+    if len(sys.argv) == 6 and sys.argv[1] == "--cpu-worker":
+        return _cpu_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -69,6 +99,8 @@ def main():
     ap.add_argument("--config", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="ensemble members per GPU (default: the config's own size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-cores", type=int, default=0, help="host cores for the CPU baseline (0 = all this process may use, "
+                                                             "at most 16)")
     ap.add_argument("--backend", default="nccl", help="collective backend for N > 1: nccl (= RCCL over xGMI, the real thing) or "
                                                       "gloo (rehearsal on a box with fewer GPUs than ranks: results staged through the host)")
     ap.add_argument("--exact-qp", action="store_true", help="not the headline: every QP solved to the box-constrained optimum "
@@ -221,7 +253,8 @@ def main():
                                  "frac": abytes / avg_launch_s / 1e9 / PEAK_HBM_GBS}},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(p)
+            cores = args.cpu_cores or min(16, len(os.sched_getaffinity(0)))
+            out["cpu_baseline"] = cpu_baseline(args.config, p, cores)
         print(json.dumps(out))
     sess.close()
     if multi:
