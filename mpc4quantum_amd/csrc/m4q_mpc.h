@@ -339,7 +339,7 @@ struct Box {       // |u| <= sat, first control also within [lo0, hi0]
   }
 };
 
-// Working set of the exact box-QP solver (see solve_box_qp): stat [T][NU] doubles, 0 free, +1 / -1 pinned at the
+// Working set of the exact box-QP solver (see box_qp_iterate): stat [T][NU] doubles, 0 free, +1 / -1 pinned at the
 // upper / lower bound.
 template <int NU>
 struct PinCtx {

@@ -1,4 +1,4 @@
-"""CPU prototype (dense, condensed) of the device's exact box-QP iteration (csrc/m4q_mpc.h solve_box_qp), to study its
+"""CPU prototype (dense, condensed) of the device's exact box-QP iteration (csrc/m4q_mpc.h box_qp_iterate), to study its
 iteration counts on the QPs of a closed loop.  Development tool; not used by the package, the tests or the bench."""
 import os
 import sys
