@@ -939,7 +939,7 @@ __device__ __forceinline__ bool box_qp_iterate(const Prov& prov, int T, S x0, co
       }
     }
     if (going && moved) r.cur_is_a = !r.cur_is_a;
-    if (r.busy && r.iters >= 100) { r.busy = false; ++r.stats.end_cap; }
+    if (r.busy && r.iters >= 100 + 2 * NU * T) { r.busy = false; ++r.stats.end_cap; }   // (the path adds at least one control per step)
     wave_sync();
   }
   return was_busy && !r.busy;
