@@ -870,3 +870,37 @@ def test_properties_at_scale(cfg, batch):
     if cfg == 2:
         assert np.array_equal(res["us"][0], res["us"][batch // 2 + 1])
     assert res["qp_solves"][:, 2:].min() == 1 and res["qp_solves"][:, 2:].max() == 1
+
+
+@pytest.mark.parametrize("cfg,batch", [(3, 65536), (4, 8192)])
+def test_properties_at_full_baseline_size(cfg, batch):
+    """BASELINE config 3 at its full single-GPU size (65,536 per-member models, T = 40) and config 4's per-GPU share of
+    the 8-way sharding, set up the way bench.py does (models built on the device from generators and per-member scales).
+    The oracle cannot follow; every member must still finish with exit code 0, keep rho_t Hermitian with unit trace,
+    respect the box and the du band, spend exactly one QP solve per warm step - and members with identical inputs placed
+    in different wavefronts must produce identical bits."""
+    p = configs.build(cfg, batch=batch, host_models=False)
+    twin = batch - 3
+    p["scales"][twin] = p["scales"][1]
+    p["x0"][twin] = p["x0"][1]
+    n, m, T, ns, d = p["dim_x"], p["dim_u"], p["horizon"], p["n_steps"], p["d"]
+    sess = m4q.EnsembleSession(batch, n, m, p["order"], T, ns, p["dt"], p["sat"], p["du"], model_per_instance=True,
+                               target_cols=ns + T + 1)
+    try:
+        sess.build_models(p["dt"], p["generators"], p["scales"])
+        sess.load_problem(None, p["x0"], p["X_targ"], p["U_targ"], p["Q"], p["R"], p["Qf"], p["plant_op0"], p["plant_ops"])
+        assert sess.path() == "real"
+        sess.run(0, ns)
+        res = sess.results()
+    finally:
+        sess.close()
+    xs, us = res["xs"], res["us"]                                  # time-major: [B, ns+1, n], [B, ns, m]
+    assert np.all(res["exit_codes"] == 0) and np.all(res["steps_done"] == ns)
+    rho = xs.reshape(batch, ns + 1, d, d)
+    assert np.abs(rho.trace(axis1=2, axis2=3) - 1).max() < 1e-10
+    assert np.abs(rho - np.swapaxes(rho.conj(), 2, 3)).max() < 1e-10
+    assert np.abs(us).max() <= p["sat"] * (1 + 1e-15)
+    assert np.abs(np.diff(us, axis=1))[:, 1:].max() <= p["du"] * (1 + 1e-12)
+    assert res["qp_solves"][:, 2:].min() == 1 and res["qp_solves"][:, 2:].max() == 1
+    assert np.array_equal(xs[1], xs[twin]) and np.array_equal(us[1], us[twin])
+    assert np.abs(us).max() > 0.5 * p["sat"]                       # (and the ensemble is really being driven)
