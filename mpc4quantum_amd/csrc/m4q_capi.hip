@@ -281,6 +281,10 @@ int m4q_session_create(const m4q_problem* p, int32_t B, int32_t device, m4q_sess
   const int exact = (p->qp_flags & M4Q_QP_EXACT_BOX) ? 1 : 0;
   int per_cu = std::max(sh->occupancy(p->plant_kind, 0, exact), s->force_complex ? 0 : sh->occupancy(p->plant_kind, 1, exact));
   if (per_cu < 1) per_cu = 1;
+  if (const char* cap = std::getenv("M4Q_WGS_PER_CU")) {       // tuning experiments: fewer resident workgroups per CU
+    const int v = std::atoi(cap);
+    if (v >= 1 && v < per_cu) per_cu = v;
+  }
   const int nquads = (B + 3) / 4;
   long resident = (long)per_cu * prop.multiProcessorCount;
   s->grid = (int)(nquads < resident ? nquads : resident);
