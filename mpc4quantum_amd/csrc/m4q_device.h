@@ -179,11 +179,11 @@ template <> __device__ __forceinline__ cplx from_real<cplx>(double r) { return m
 
 // ---- term emitter: a compile-time list of multiply-accumulate terms
 //        acc[IDX::acc(q)] += opA(lane_{IDX::lane(q)}(a[IDX::a(q)])) * opB(b[IDX::b(q)]),   q in [Q0, QN)
-// is cut into asm statements of up to 9 (double) / 4 (cplx) terms.  DOT: every term of the list adds into
+// is cut into asm statements of up to 16 (double) / 4 (cplx) terms.  DOT: every term of the list adds into
 // acc[IDX::acc(Q0)] (dependent FMA chains are free on gfx950, so no partial sums); otherwise a statement
 // never holds two terms with the same accumulator (IDX::distinct = guaranteed run of distinct accumulators).
 template <class S> struct ChunkMax { static constexpr int value = 4; };
-template <> struct ChunkMax<double> { static constexpr int value = 9; };
+template <> struct ChunkMax<double> { static constexpr int value = 16; };
 
 template <class IDX, bool CA, bool CB, bool DOT, int Q0, int NA, int NB, int NC, size_t... I>
 __device__ __forceinline__ void emit_block(double (&acc)[NA], const double (&a)[NB], const double (&b)[NC], std::index_sequence<I...>) {
