@@ -195,9 +195,30 @@ __device__ __forceinline__ void emit_block(cplx (&acc)[NA], const cplx (&a)[NB],
   if constexpr (DOT) cdotN<CA, CB, IDX::lane(Q0 + (int)I)...>(acc[IDX::acc(Q0)], a[IDX::a(Q0 + (int)I)]..., b[IDX::b(Q0 + (int)I)]...);
   else cmacN<CA, CB, IDX::lane(Q0 + (int)I)...>(acc[IDX::acc(Q0 + (int)I)]..., a[IDX::a(Q0 + (int)I)]..., b[IDX::b(Q0 + (int)I)]...);
 }
+// two runs of ND distinct accumulators in one statement (real only): term i adds into the accumulator of term i % ND
+template <class IDX, int Q0, int ND, int NA, int NB, int NC, size_t... I, size_t... J>
+__device__ __forceinline__ void emit_block_wrap(double (&acc)[NA], const double (&a)[NB], const double (&b)[NC], std::index_sequence<I...>,
+                                                std::index_sequence<J...>) {
+  fmac2xN<IDX::lane(Q0 + (int)J)...>(acc[IDX::acc(Q0 + (int)I)]..., a[IDX::a(Q0 + (int)J)]..., b[IDX::b(Q0 + (int)J)]...);
+}
+template <class IDX, int Q0, int ND>
+constexpr bool wrap_ok() {       // the second run must hit the same accumulators in the same order
+  for (int i = 0; i < ND; ++i)
+    if (IDX::acc(Q0 + i) != IDX::acc(Q0 + ND + i)) return false;
+  return true;
+}
+
 template <class IDX, bool CA, bool CB, bool DOT, int Q0, int QN, class S, int NA, int NB, int NC>
 __device__ __forceinline__ void emit_terms(S (&acc)[NA], const S (&a)[NB], const S (&b)[NC]) {
   constexpr int left = QN - Q0;
+  if constexpr (!DOT && sizeof(S) == sizeof(double) && IDX::distinct >= 2 && IDX::distinct <= 9 && left >= 2 * IDX::distinct) {
+    if constexpr (wrap_ok<IDX, Q0, IDX::distinct>()) {
+      constexpr int ND = IDX::distinct;
+      emit_block_wrap<IDX, Q0, ND>(acc, a, b, std::make_index_sequence<ND>{}, std::make_index_sequence<2 * ND>{});
+      emit_terms<IDX, CA, CB, DOT, Q0 + 2 * ND, QN>(acc, a, b);
+      return;
+    }
+  }
   if constexpr (left > 0) {
     constexpr int cap0 = ChunkMax<S>::value;
     constexpr int cap = DOT ? cap0 : (cap0 < IDX::distinct ? cap0 : IDX::distinct);
