@@ -211,7 +211,7 @@ constexpr bool wrap_ok() {       // the second run must hit the same accumulator
 template <class IDX, bool CA, bool CB, bool DOT, int Q0, int QN, class S, int NA, int NB, int NC>
 __device__ __forceinline__ void emit_terms(S (&acc)[NA], const S (&a)[NB], const S (&b)[NC]) {
   constexpr int left = QN - Q0;
-  if constexpr (!DOT && sizeof(S) == sizeof(double) && IDX::distinct >= 2 && IDX::distinct <= 9 && left >= 2 * IDX::distinct) {
+  if constexpr (!DOT && sizeof(S) == sizeof(double) && IDX::distinct >= 2 && IDX::distinct <= 16 && left >= 2 * IDX::distinct) {
     if constexpr (wrap_ok<IDX, Q0, IDX::distinct>()) {
       constexpr int ND = IDX::distinct;
       emit_block_wrap<IDX, Q0, ND>(acc, a, b, std::make_index_sequence<ND>{}, std::make_index_sequence<2 * ND>{});
