@@ -321,7 +321,9 @@ __device__ __forceinline__ S qrow_times(const S* Qt, S v, int j) {
 //   P  <- Q + Kx^H R Kx + Sx^H P Sx ;  p <- -Q r + Kx^H R k + Sx^H (P s + p)   lqr.py:64-65
 // gains layout: [t][col 0..NX][NU]  (col NX holds k); the view is positioned at the instance.
 // ---------------------------------------------------------------------------------------------
-#ifndef M4Q_NO_PHASE
+// Phase marks of the sweeps.  -DM4Q_SCHED_PHASES turns them into scheduling barriers (an early build needed them against
+// spills; with today's statements the scheduler does better without: 53.3 -> 52.5 ms on config 3, d=4 7.92e8 -> 8.04e8).
+#ifdef M4Q_SCHED_PHASES
 #define M4Q_PHASE() __builtin_amdgcn_sched_barrier(0)
 #else
 #define M4Q_PHASE() ((void)0)
