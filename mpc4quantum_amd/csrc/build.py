@@ -69,7 +69,9 @@ if __name__ == "__main__":
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--jobs", type=int, default=None)
     ap.add_argument("--shfl", action="store_true", help="debug build: row broadcasts through ds_bpermute instead of DPP")
-    ap.add_argument("--define", action="append", default=[], help="extra -D for the kernel objects (tuning experiments)")
+    ap.add_argument("--define", action="append", default=[], help="extra -D for the kernel objects (tuning experiments; forces a rebuild)")
+    ap.add_argument("--flag", action="append", default=[], help="extra compiler flag for the kernel objects, e.g. "
+                                                                "--flag=-mllvm --flag=-amdgpu-sched-strategy=max-ilp (forces a rebuild)")
     a = ap.parse_args()
-    extra = (["-DM4Q_BCAST_SHFL"] if a.shfl else []) + ["-D" + d for d in a.define]
+    extra = (["-DM4Q_BCAST_SHFL"] if a.shfl else []) + ["-D" + d for d in a.define] + list(a.flag)
     print(build(a.force or bool(extra), a.jobs, extra))
