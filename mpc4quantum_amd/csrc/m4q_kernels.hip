@@ -584,24 +584,19 @@ __global__ __launch_bounds__(64) M4Q_OCC void qp_kernel(QpArgs a) {
       hi0[k] = band ? up + a.du : a.sat;
     }
     const cplx x0 = a.x_init[b * NX + j];
-    const double obj = rollout_forward<cplx, NX, NU, true>(prov, T, x0, win, cost, a.flags, gains, a.sat, lo0, hi0, Xo, Uo, j, st,
+    const bool exact = (a.flags & QP_EXACT_BOX) != 0;
+    // the exact solver ping-pongs between two trajectory pairs of ONE allocation (rows pick theirs by lane offset):
+    // X_alt = [B][T+1][n] twice, U_alt likewise; the clipped rollout, its starting point, goes straight into the first
+    const GView Xa = gview(exact ? a.X_alt : a.X_opt, q0 * sX, gl * sX);
+    const GView Ua = gview(exact ? a.U_alt : a.U_opt, q0 * sU, gl * sU);
+    const double obj = rollout_forward<cplx, NX, NU, true>(prov, T, x0, win, cost, a.flags, gains, a.sat, lo0, hi0, Xa, Ua, j, st,
                                                               u_first);
     wave_sync();
     double obj_out = obj;
-    if (a.flags & QP_EXACT_BOX) {
-      // the solver ping-pongs between two trajectory pairs of ONE allocation (rows pick theirs by lane offset):
-      // X_alt = [B][T+1][n] twice, U_alt likewise
-      const GView Xa = gview(a.X_alt, q0 * sX, gl * sX);
-      const GView Ua = gview(a.U_alt, q0 * sU, gl * sU);
+    if (exact) {
       const GView Xb = gview(a.X_alt, q0 * sX, gl * sX + (unsigned)a.B * sX);
       const GView Ub = gview(a.U_alt, q0 * sU, gl * sU + (unsigned)a.B * sU);
       const GView stat = gview(a.pin_stat, q0 * sU, gl * sU);
-      if (st) {
-        for (int t = 0; t <= T; ++t) Xa.st<cplx>(t * NX + j, Xo.ld<cplx>(t * NX + j));
-        if (j == 0)
-          for (int i = 0; i < T * NU; ++i) Ua.st<double>(i, Uo.ld<double>(i));
-      }
-      wave_sync();
       PinCtx<NU> pin;
       pin.stat = stat;
       pin.box.sat = a.sat;

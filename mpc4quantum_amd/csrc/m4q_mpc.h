@@ -618,10 +618,11 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
     }
     return o;
   };
-  Ops cur = load(0);
-  for (int t = 0; t < T; ++t) {
+  // one horizon index: `cur` holds its operands, those of the next index are fetched into `nxt` meanwhile.  The loop
+  // below runs two indices per trip with the two operand sets swapping roles, so that no set is ever copied.
+  auto step = [&](int t, const Ops& cur, Ops& nxt) {
     M4Q_NO_HOIST();
-    const Ops nxt = load(t + 1 < T ? t + 1 : t);
+    nxt = load(t + 1 < T ? t + 1 : t);
     S ax, Brow[NU], dlt;
     prov.rows(cur.lin, x, ax, Brow, dlt);
     M4Q_PHASE();
@@ -677,9 +678,15 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
         }
       }
     }
-    cur = nxt;
     M4Q_PHASE();
+  };
+  Ops opsA = load(0), opsB;
+  int t = 0;
+  for (; t + 1 < T; t += 2) {
+    step(t, opsA, opsB);
+    step(t + 1, opsB, opsA);
   }
+  if (t < T) step(t, opsA, opsB);
   if constexpr (WANT_COST) {
     if (!ref) {
       const S e = csub(x, win.xbm.ld<S>(T * NX + j));
