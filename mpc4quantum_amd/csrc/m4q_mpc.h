@@ -383,20 +383,27 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
     pin->nchg = 0;
     if (pin->any_derive) lam = qrow_times<NX>(cost.q(T, T), csub(pin->Xk.template ld<S>(T * NX + j), xb_next), j);
   }
-  // operands of horizon index t are fetched while index t+1 is being worked on
-  typename Prov::Lin lin = prov.fetch(T - 1);
-  S xb = win.xbm.ld<S>((T - 1) * NX + j);
-  double ub[NU];
+  // operands of horizon index t are fetched while index t+1 is being worked on.  The loop below runs two indices per
+  // trip: the two operand sets and the two copies of (P, p) swap roles, so that neither is ever copied.
+  struct Ops {
+    typename Prov::Lin lin;
+    S xb;
+    double ub[NU];
+  };
+  auto load = [&](int t) __attribute__((always_inline)) {
+    Ops o;
+    o.lin = prov.fetch(t);
+    o.xb = win.xbm.ld<S>(t * NX + j);
 #pragma unroll
-  for (int k = 0; k < NU; ++k) ub[k] = win.ubm.ld<double>((T - 1) * NU + k);
-  for (int t = T - 1; t >= 0; --t) {
+    for (int k = 0; k < NU; ++k) o.ub[k] = win.ubm.ld<double>(t * NU + k);
+    return o;
+  };
+  auto step = [&](int t, const Ops& cur, Ops& nxt, const S (&Pc)[NX], const S pv, S (&Pn)[NX], S& pv_out) __attribute__((always_inline)) {
     M4Q_NO_HOIST();
-    const int tn = t > 0 ? t - 1 : 0;
-    const typename Prov::Lin lin_n = prov.fetch(tn);
-    const S xb_n = win.xbm.ld<S>(tn * NX + j);
-    double ub_n[NU];
-#pragma unroll
-    for (int k = 0; k < NU; ++k) ub_n[k] = win.ubm.ld<double>(tn * NU + k);
+    nxt = load(t > 0 ? t - 1 : 0);
+    const typename Prov::Lin& lin = cur.lin;
+    const S xb = cur.xb;
+    const double (&ub)[NU] = cur.ub;
 
     S Ac[NX];
     prov.col(lin, Ac);
@@ -545,7 +552,6 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
       }
     }
     const S* Qt = cost.q(t, T);
-    S Pn[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) Pn[i] = Qt[i * NX + j];
     matmul_cols_hn_acc<NX>(Pn, Ac, PSc);                       // + Sx^H P Sx
@@ -555,16 +561,29 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
 #pragma unroll
     for (int k = 0; k < NU; ++k) cmac_cj(pn, Kx[k], Rk[k]);
     if (ref) pn = csub(pn, qrow_times<NX>(Qt, xb, j));        // - Q xbar_t   (lqr.py:54-58)
-#pragma unroll
-    for (int i = 0; i < NX; ++i) Pc[i] = Pn[i];
-    pv = pn;
-    // rotate the prefetched operands in
+    pv_out = pn;
     xb_next = xb;
-    xb = xb_n;
-    lin = lin_n;
-#pragma unroll
-    for (int k = 0; k < NU; ++k) ub[k] = ub_n[k];
     M4Q_PHASE();
+  };
+  S Pd[NX];
+  S pd = zero_of<S>();
+  Ops opsA = load(T - 1), opsB;
+  if constexpr (sizeof(S) == sizeof(double)) {
+    int t = T - 1;
+    for (; t >= 1; t -= 2) {
+      step(t, opsA, opsB, Pc, pv, Pd, pd);
+      step(t - 1, opsB, opsA, Pd, pd, Pc, pv);
+    }
+    if (t == 0) step(0, opsA, opsB, Pc, pv, Pd, pd);
+  } else {
+    // complex path: one index per trip and plain copies (twice the registers per matrix: the two-index form does not pay)
+    for (int t = T - 1; t >= 0; --t) {
+      step(t, opsA, opsB, Pc, pv, Pd, pd);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Pc[i] = Pd[i];
+      pv = pd;
+      opsA = opsB;
+    }
   }
 }
 
@@ -605,7 +624,7 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
     S Kx[NU];
     double kre[NU];
   };
-  auto load = [&](int t) {
+  auto load = [&](int t) __attribute__((always_inline)) {
     Ops o;
     o.lin = prov.fetch(t);
     o.xb = win.xbm.ld<S>(t * NX + j);
@@ -620,7 +639,7 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
   };
   // one horizon index: `cur` holds its operands, those of the next index are fetched into `nxt` meanwhile.  The loop
   // below runs two indices per trip with the two operand sets swapping roles, so that no set is ever copied.
-  auto step = [&](int t, const Ops& cur, Ops& nxt) {
+  auto step = [&](int t, const Ops& cur, Ops& nxt) __attribute__((always_inline)) {
     M4Q_NO_HOIST();
     nxt = load(t + 1 < T ? t + 1 : t);
     S ax, Brow[NU], dlt;
