@@ -62,7 +62,10 @@ extern "C" {
 #define M4Q_OPT_FORCE_COMPLEX 1
 
 /* exit codes per instance (mpc.py:130,195,202,291): 0 normal, 1 exit_condition (host side),
- * 2 reserved (solver warning: cannot occur without OSQP), 3 non-finite objective */
+ * 2 solver gave up (mpc.py:183-197 turns a cvxpy/OSQP warning into this; here: an M4Q_QP_EXACT_BOX solve that stopped at
+ *   its iteration cap - the clipped Riccati solve cannot produce it), 3 non-finite objective (mpc.py:200-203; also where
+ *   the reference would raise on NaN data: a batched engine cannot raise for one member).
+ * A non-zero code ends that member's run at the step where it occurred: steps_done says how many steps are valid. */
 
 typedef struct m4q_problem {
   int32_t dim_x;   /* n = d*d: 4, 9 or 16; also 8 (two reduced qubit states, experiment.py:238-306) with M4Q_PLANT_NONE */

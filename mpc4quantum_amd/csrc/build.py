@@ -16,7 +16,9 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(PKG, "libm4q_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-command-line-argument"]
-HEADERS = ["m4q_device.h", "m4q_mpc.h", "m4q_args.h", "m4q_shapes.inc", os.path.join("..", "..", "include", "m4q.h")]
+HEADERS = ["m4q_device.h", "m4q_dpp_gen.h", "m4q_mpc.h", "m4q_args.h", "m4q_shapes.inc",
+           os.path.join("..", "..", "include", "m4q.h")]
+STAMP = os.path.join(OBJ, "flags.stamp")       # the extra flags the objects in OBJ were built with
 
 
 def shapes():
@@ -40,8 +42,20 @@ def run(cmd):
 
 
 def build(force=False, jobs=None, extra=()):
+    """Objects built with other extra flags than the ones requested now (experiment / ablation / debug builds write to the
+    same files) are rebuilt: a plain build() never ships the leftovers of an experiment."""
     os.makedirs(OBJ, exist_ok=True)
     hdrs = [os.path.join(HERE, h) for h in HEADERS]
+    gen = os.path.join(HERE, "m4q_dpp_gen.h")
+    if stale(gen, [os.path.join(HERE, "gen_dpp.py")]):          # the generated DPP statements follow their generator
+        text = run([sys.executable, os.path.join(HERE, "gen_dpp.py")])
+        if not os.path.exists(gen) or open(gen).read() != text:  # (rewritten - and everything rebuilt - only if they differ)
+            with open(gen, "w") as f:
+                f.write(text)
+    want = " ".join(extra)
+    have = open(STAMP).read() if os.path.exists(STAMP) else None
+    if have != want:
+        force = True
     jobs_list = []
     objs = []
     for nx, nu, order in shapes():
@@ -61,6 +75,8 @@ def build(force=False, jobs=None, extra=()):
             list(ex.map(run, jobs_list))
     if force or jobs_list or stale(LIB, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    with open(STAMP, "w") as f:
+        f.write(want)
     return LIB
 
 

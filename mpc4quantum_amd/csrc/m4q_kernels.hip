@@ -287,6 +287,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
     // Clipped mode: every running row, each pass.  EXACT: a row's solve spans several passes (one active-set iteration
     // per pass), so that no row waits for the slowest solve of its wavefront.
     bool solved = running;
+    bool capped = false;         // EXACT: the solve stopped at its iteration cap (not converged): exit code 2
     if constexpr (EXACT) {
       PinCtx<NU> pin;
       pin.stat = pin_stat;
@@ -310,6 +311,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
       if (__any(qp.busy)) ++qp_passes;
       const bool ended = box_qp_iterate<S, NX, NU>(prov, T, x_cur, win, cost, a.flags, gains, pin, Xo, Uo, Xalt, Ualt, qp, j, jj, lane_ok);
       solved = running && (ended || bad_start);
+      capped = solved && !bad_start && qp.stats.end_cap > 0;
       chk = qp.Jk;
       GView Xs = Xo, Us = Uo;
       Xs.off = qp.cur_is_a ? Xo.off : Xalt.off;
@@ -344,7 +346,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
                                                 !use_ls, &Xg, &Ug);
     }
     wave_sync();
-    const bool fail = !finite_d(chk);                      // mpc.py:200-203
+    // exit code 3: non-finite objective (mpc.py:200-203).  exit code 2 (EXACT only): the solver gave up - the analogue of
+    // the solver warning mpc.py:183-197 turns into code 2; either way the member's run ends here (mpc.py:196,203,231).
+    const bool fail = !finite_d(chk) || capped;
     if (solved) ++iter;
     double alpha = 1.0;
     bool fin = true;
@@ -383,7 +387,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
 
     // ---- rows that finished their MPC step: apply, propagate, shift ----
     if (__any(step_done)) {
-      if (step_done && fail) code = 3;
+      if (step_done && fail) code = finite_d(chk) ? 2 : 3;
       if (step_done && jj == 0) a.qp_solves[b * a.n_steps + step] = iter;
       const bool ok = step_done && !fail;
       // apply U_opt[:, 0] (mpc.py:250), propagate the plant (mpc.py:256-260)

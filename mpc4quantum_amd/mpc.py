@@ -59,6 +59,14 @@ def isinf_warning():
                   "can regularize the problem, or run with verbose=True for more information.")
 
 
+def solver_warning():
+    """Exit code 2 (mpc.py:183-197: a solver warning ends the run).  Without OSQP the one solver that can give up is the exact
+    box-QP iteration (exact_qp=True) stopping at its iteration cap."""
+    import warnings
+    warnings.warn("The exact box-QP solve stopped at its iteration cap before reaching the KKT point (exit code 2); "
+                  "the horizon QP is too ill-conditioned for fp64 - shorten the horizon or use the clipped solve.")
+
+
 def complex_to_real(z):
     """mpc.py:87-89: complex vector of length n -> [Re; Im] of length 2n."""
     return np.concatenate((np.real(z), np.imag(z)))
@@ -122,10 +130,13 @@ def _trim(xs, us, code, done):
 
 
 def mpc(x0, dim_u, order, X_targ, U_targ, clock, experiment, model, Q, R, Qf, sat=None, du=None, max_iter=100,
-        exit_condition=None, streaming=False, warm_start=True, progress_bar=True, verbose=False, exact_qp=False):
+        exit_condition=None, streaming=False, warm_start=True, progress_bar=True, verbose=False, exact_qp=False,
+        qp_flags=None):
     """Drop-in for mpc4quantum.mpc.mpc (mpc.py:128-304): returns ([xs, us], model, exit_code).
     exact_qp (extension): solve each QP to the box-constrained optimum, as the reference's OSQP call does, instead of
-    clipping the Riccati rollout (identical whenever no bound is active)."""
+    clipping the Riccati rollout (identical whenever no bound is active).
+    qp_flags (extension): M4Q_QP_* bits; _lib.QP_REF_LQR runs the loop around the arithmetic of the reference's lqr.py as
+    written, which is what tests/golden/mpc_loop.npz (the reference's own mpc.py around its own lqr.py) pins."""
     mf = int(clock.measure_freq)
     x0 = np.asarray(x0, dtype=np.complex128).reshape(-1)
     lift_x0 = np.asarray(experiment.lift(x0), dtype=np.complex128).reshape(-1)
@@ -138,8 +149,8 @@ def mpc(x0, dim_u, order, X_targ, U_targ, clock, experiment, model, Q, R, Qf, sa
     cols = min(X_targ.shape[1], ns + T + 1)
     fused = _native_plant(experiment) and exit_condition is None and not streaming
     kind = experiment.plant_kind if fused else _lib.PLANT_NONE
-    sess = EnsembleSession(1, n, dim_u, order, T, ns, clock.dt, sat, du, max_iter, warm_start, plant_kind=kind,
-                           target_cols=cols, measure_freq=mf, exact_qp=exact_qp)
+    sess = EnsembleSession(1, n, dim_u, order, T, ns, clock.dt, sat, du, max_iter, warm_start, qp_flags=qp_flags,
+                           plant_kind=kind, target_cols=cols, measure_freq=mf, exact_qp=exact_qp)
     try:
         op0, ops = experiment.operators() if fused else (None, None)
         sess.load_problem(np.hstack([A_x, A_u])[None], lift_x0[None], X_targ, U_targ, Q, R, Qf, op0, ops)
@@ -149,7 +160,9 @@ def mpc(x0, dim_u, order, X_targ, U_targ, clock, experiment, model, Q, R, Qf, sa
             code, done = int(res["exit_codes"][0]), int(res["steps_done"][0])
             if code == 3:
                 isinf_warning()                                                                # mpc.py:200-203
-            clock.set_endsim(done if code else done)
+            if code == 2:
+                solver_warning()                                                               # mpc.py:193-196
+            clock.set_endsim(done)
             return _trim(res["xs"][0].T, res["us"][0].T, code, done), model, code
         # host plant: one launch per MPC step, the plant (and lift/proj) evaluated by the caller's object
         xs = [x0]
@@ -171,6 +184,8 @@ def mpc(x0, dim_u, order, X_targ, U_targ, clock, experiment, model, Q, R, Qf, sa
                 code = dev_code
                 if code == 3:
                     isinf_warning()
+                if code == 2:
+                    solver_warning()
                 break
             u = sess.download(_lib.F_US, (1, ns, dim_u))[0, step]
             us.append(u)

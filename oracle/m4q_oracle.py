@@ -575,13 +575,17 @@ class OracleQCoupledExperiment(OracleQExperiment):
 
 
 def mpc(x0, dim_u, order, X_targ, U_targ, clock, experiment, model, Q, R, Qf, sat=None, du=None, max_iter=100,
-        exit_condition=None, warm_start=True, qp_mode="qp", count=None, trace=None, streaming=False):
+        exit_condition=None, warm_start=True, qp_mode="qp", count=None, trace=None, streaming=False, solve_trace=None,
+        start=None, stop=None):
     """Receding-horizon loop restating mpc.py:128-304 for streaming == False (any clock.measure_freq),
     with ``quad_program`` being the Riccati solver above (qp_mode "qp"), the lqr.py restatement
     (qp_mode "lqr") or the exact box-constrained solve (qp_mode "exact", BVLS).  Keeps the quirks: u_prev from
     U_ref at steps 0 and 1 (:185), applied control U_opt[:,0] (:250), target window lag (:276-277), exit codes 0/1/3 and the dropped last entry
     (:294-304).  ``count`` (a list) receives the number of QP solves per MPC step; ``trace`` (a list) receives
-    (X_guess, U_guess) as they stand when each MPC step starts."""
+    (X_guess, U_guess) as they stand when each MPC step starts; ``solve_trace`` (a list) receives (step, X_guess,
+    U_guess) at EVERY QP solve (what the reference hands to get_model_along_traj, mpc.py:175).
+    Teacher forcing (tests): ``start`` = dict(step, xs, us, X_guess, U_guess) resumes at MPC step ``step`` from the given
+    history (xs (n, step+1), us (m, step)) and SQP guess; ``stop`` ends the run before MPC step ``stop``."""
     exit_code = 0
     T = clock.horizon
     lift_x0 = np.asarray(experiment.lift(x0), dtype=complex)
@@ -596,12 +600,26 @@ def mpc(x0, dim_u, order, X_targ, U_targ, clock, experiment, model, Q, R, Qf, sa
     wm = OracleWrapModel(*model.get_discrete(), dim_u, order)
     xs[0] = np.asarray(x0, dtype=complex)
     step = 0
-    for step in range(clock.n_steps):
+    first = 0
+    if start is not None:
+        first = int(start["step"])
+        for i in range(first + 1):
+            xs[i] = np.asarray(start["xs"][:, i], dtype=complex)
+        for i in range(first):
+            us[i] = np.asarray(start["us"][:, i], dtype=float)
+        X_guess = np.array(start["X_guess"], dtype=complex)
+        U_guess = np.array(start["U_guess"], dtype=float)
+        if first > 0:                                            # the window left behind by step first-1 (mpc.py:276-277)
+            X_ref = np.atleast_2d(X_targ[:, first - 1:first + T])
+            U_ref = np.atleast_2d(U_targ[:, first - 1:first - 1 + T])
+    for step in range(first, clock.n_steps if stop is None else min(int(stop), clock.n_steps)):
         n_iter = 0
         done = False
         if trace is not None:
             trace.append((X_guess.copy(), U_guess.copy()))
         while not done and n_iter < max_iter:
+            if solve_trace is not None:
+                solve_trace.append((step, X_guess.copy(), U_guess.copy()))
             A_ls, B_ls, D_ls = wm.get_model_along_traj(X_guess, U_guess, clock.ts_horizon(step))
             u_prev = us[step - 1] if step > 1 else U_ref[:, 0].reshape(-1, 1)
             x_now = experiment.lift(xs[step])
@@ -611,8 +629,8 @@ def mpc(x0, dim_u, order, X_targ, U_targ, clock, experiment, model, Q, R, Qf, sa
                 X_opt, U_opt, obj = exact_quad_program(x_now, X_ref, U_ref, Q_ls, R_ls, A_ls, B_ls, D_ls, u_prev, sat, du)
             else:
                 X_opt, U_opt, obj, _ = quad_program(x_now, X_ref, U_ref, Q_ls, R_ls, A_ls, B_ls, D_ls, u_prev, sat, du)
-            if not np.isfinite(obj):
-                exit_code = 3
+            if np.isinf(obj):                                    # mpc.py:200: isinf, NOT "not isfinite" - a NaN objective
+                exit_code = 3                                    # goes on (and pinv raises LinAlgError at the next solve)
                 break
             if step > (1 if warm_start else np.inf):
                 alpha = 1

@@ -2,9 +2,14 @@
 
 Run once in the build container (where /root/reference exists):
     python tests/golden/make_golden.py
-(`python tests/golden/make_golden.py dmdc` regenerates only dmdc.npz.)
+(`python tests/golden/make_golden.py dmdc` regenerates only dmdc.npz, `... mpc_loop` only mpc_loop.npz.)
 The reference modules are loaded by file path (the package __init__ needs qutip/cvxpy, which are
-absent); only linearize.py, lqr.py, model.py and vectorize.py are executed.  Two harness-side
+absent); linearize.py, lqr.py, model.py, vectorize.py and - for mpc_loop.npz - mpc.py are executed.
+mpc.py does `from .optimize import quad_program` (cvxpy + OSQP, absent): a stub module of that name forwards
+to the reference's OWN lqr.quad_program (lqr.py:14, which takes no Delta_ls), so the closed loop that runs is
+the reference's driver (mpc.py:128-304: SQP iteration, iqp_line_search, shift_guess, exit codes, trimming,
+StepClock) around the reference's Riccati arithmetic.  The plant is a harness object (the reference's needs
+qutip): the exact held-control propagator of the same ODE.  Two harness-side
 shims restore NumPy-1 names the reference uses (np.product, np.math); an inert module named
 ``qutip`` satisfies vectorize.py's import (only vectorize_me touches it, and is not called).
 Nothing from the reference is copied: the fixtures hold inputs and the reference's outputs.
@@ -200,9 +205,220 @@ def golden_dmdc():
     print("wrote dmdc.npz")
 
 
+def load_reference_mpc():
+    """The reference's mpc.py, loaded by path with `.optimize` stubbed to the reference's lqr.quad_program."""
+    mods = load_reference()
+    lqr = mods["lqr"]
+    opt = types.ModuleType("m4q_reference.optimize")
+
+    def quad_program(x_init, X_bm, U_bm, Q_ls, R_ls, A_ls, B_ls, Delta_ls, u_prev=None, sat=None, du=None, verbose=False):
+        return lqr.quad_program(x_init, X_bm, U_bm, Q_ls, R_ls, A_ls, B_ls, u_prev, sat, du, verbose)
+    opt.quad_program = quad_program
+    sys.modules["m4q_reference.optimize"] = opt
+    import matplotlib
+    matplotlib.use("Agg")
+    spec = importlib.util.spec_from_file_location("m4q_reference.mpc", REF + "mpc.py")
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["m4q_reference.mpc"] = mod
+    spec.loader.exec_module(mod)
+    mods["mpc"] = mod
+    return mods
+
+
+class HeldPlant:
+    """Harness plant with the duck type mpc.py needs (experiment.py:29-49): identity lift/proj, simulate(x0, ts, u_fn)
+    -> (n, len(ts)).  rho' = -i[H0 + sum_k u_k(t) H_k, rho] + growth * rho, u held on each [ts[i], ts[i+1]) (mpc.py:258
+    hands over interp1d(kind='previous')), solved exactly with scipy.linalg.expm."""
+
+    def __init__(self, H0, Hs, growth=0.0):
+        self.H0, self.Hs, self.growth = H0, list(Hs), float(growth)
+
+    @staticmethod
+    def lift(x):
+        return x
+
+    @staticmethod
+    def proj(z):
+        return z
+
+    def simulate(self, x0, ts, u_fn):
+        from scipy.linalg import expm
+        d = self.H0.shape[0]
+        out = [np.reshape(x0, -1)]
+        for a, b in zip(ts[:-1], ts[1:]):
+            u = np.reshape(u_fn(0.5 * (a + b)), -1)
+            H = self.H0 + sum(float(u[k]) * Hk for k, Hk in enumerate(self.Hs))
+            U = expm(-1j * (b - a) * H)
+            out.append((np.exp(self.growth * (b - a)) * (U @ out[-1].reshape(d, d) @ U.conj().T)).reshape(-1))
+        return np.stack(out, axis=1)
+
+
+def rx(theta):
+    c, s = np.cos(theta / 2), np.sin(theta / 2)
+    return np.array([[c, -1j * s], [-1j * s, c]])
+
+
+def loop_cases():
+    """Closed-loop scenarios with the parameters of the reference's tests (tests/test_mpc4quantum.py:607-670 qubit,
+    :504-564 transmon, :399-466 coupled), shortened where the full size adds nothing."""
+    def proj(d, i):
+        P = np.zeros((d, d), dtype=complex)
+        P[i, i] = 1
+        return P
+    cases = {}
+    # qubit: model exact, plant detuned by 1 % (test_mpc4quantum.py:638)
+    wq = 2 * np.pi * 4
+    sat = 2 * np.pi * 0.1
+    r = rx(1e-4)
+    qubit = dict(d=2, m=1, dt=1.0, H_model=[0.0 * SZ, 0.5 * SX], H_plant=[0.5 * (0.99 * wq - wq) * SZ, 0.5 * SX],
+                 x0=(r @ proj(2, 0) @ r.conj().T).reshape(-1), target=proj(2, 1).reshape(-1), sat=sat, du=0.5 * sat,
+                 Qdiag=[1.0, 0, 0, 1.0], R=1e-2 / sat ** 2)
+    cases["qubit_o1"] = dict(qubit, order=1, T=10, n_steps=20)
+    cases["qubit_o2_mf5"] = dict(qubit, order=2, T=10, n_steps=20, measure_freq=5)
+    cases["qubit_o1_cold_cap4"] = dict(qubit, order=1, T=10, n_steps=6, warm_start=False, max_iter=4)
+    cases["qubit_o1_exit_step3"] = dict(qubit, order=1, T=10, n_steps=12, exit_index=3, exit_thr=0.7)
+    cases["qubit_o1_exit_step0"] = dict(qubit, order=1, T=10, n_steps=5, exit_index=3, exit_thr=-1.0)
+    cases["qubit_o1_inf_step0"] = dict(qubit, order=1, T=10, n_steps=5, x0_scale=1e200)
+    cases["qubit_o1_inf_later"] = dict(qubit, order=1, T=10, n_steps=12, growth=60.0)
+    cases["qubit_o1_nan"] = dict(qubit, order=1, T=10, n_steps=3, x0_scale=np.nan)
+    # transmon (test_mpc4quantum.py:504-564, util_qubits.py:92-111): model anharmonicity 5 % off the plant's
+    dt = 0.25
+    alpha = -2 * np.pi * 0.1 / dt
+    a = np.diag(np.sqrt(np.arange(1, 3)), 1).astype(complex)
+    HX, HY = 0.5 * (a.conj().T + a), 0.5j * (a.conj().T - a)
+    sat3 = 2 * np.pi * 0.25
+    r3 = np.identity(3, dtype=complex)
+    r3[:2, :2] = rx(1e-4)
+    transmon = dict(d=3, m=2, dt=dt, H_model=[1.05 * alpha * proj(3, 2), HX, HY], H_plant=[alpha * proj(3, 2), HX, HY],
+                    x0=(r3 @ proj(3, 0) @ r3.conj().T).reshape(-1), target=proj(3, 1).reshape(-1), sat=sat3, du=0.5 * sat3,
+                    Qdiag=[1.0, 0, 0, 0, 1.0, 0, 0, 0, 0], R=1e-3 / sat3 ** 2)
+    cases["transmon_o1"] = dict(transmon, order=1, T=12, n_steps=6)
+    cases["transmon_o2_mf2_cap5"] = dict(transmon, order=2, T=8, n_steps=4, measure_freq=2, max_iter=5)
+    # two coupled qubits (test_mpc4quantum.py:399-466, util_qubits.py:19-36): crosstalk 10 % off in the model
+    sat4 = 2 * np.pi * 0.05
+    Hc = [np.kron(SZ, SZ), np.kron(SY, I2), np.kron(I2, SY), np.kron(SZ, I2)]
+    coupled = dict(d=4, m=3, dt=dt, H_model=[1.1 * Hc[0]] + Hc[1:], H_plant=Hc, x0=None, target=proj(4, 1).reshape(-1),
+                   sat=sat4, du=sat4, Qdiag=[1.0 if i % 5 == 0 else 0.0 for i in range(16)], R=1e-3)
+    r4 = np.kron(rx(1e-4), rx(2e-4))
+    coupled["x0"] = (r4 @ proj(4, 0) @ r4.conj().T).reshape(-1)
+    cases["coupled_o1_cap6"] = dict(coupled, order=1, T=8, n_steps=4, max_iter=6)
+    return cases
+
+
+def golden_mpc_loop():
+    """(6) the reference's closed-loop driver, mpc.py:101-125 (iqp_line_search) and :128-304 (mpc), run as described in the
+    module docstring.  Recorded per scenario: every input, the returned xs / us / exit_code, clock.ts_sim, and - through a
+    recording subclass of the reference's WrapModel bound in mpc.py's namespace - the SQP guess (X_guess, U_guess) handed
+    to get_model_along_traj at EVERY QP solve with the MPC step it belongs to."""
+    ref = load_reference_mpc()
+    lin, mdl, vec, rmpc = ref["linearize"], ref["model"], ref["vectorize"], ref["mpc"]
+    out = {}
+
+    # ---- iqp_line_search on seeded inputs: diagonal costs and dense Hermitian costs
+    rng = np.random.default_rng(20211015)
+    for d, m, T in ((2, 1, 5), (3, 2, 4), (4, 3, 3)):
+        n = d * d
+        for tag in ("diag", "dense"):
+            def herm(k, real=False):
+                M = rng.standard_normal((k, k)) + (0 if real else 1j * rng.standard_normal((k, k)))
+                return M @ M.conj().T + np.identity(k)
+            if tag == "diag":
+                Q, Qf, R = np.diag(rng.uniform(0, 2, n)), np.diag(rng.uniform(0, 2, n)), np.diag(rng.uniform(0.1, 1, m))
+            else:
+                Q, Qf, R = herm(n), herm(n), herm(m, real=True)
+            Q_ls, R_ls = [Q] * T + [Qf], [R] * T
+            X = [rng.standard_normal((n, T + 1)) + 1j * rng.standard_normal((n, T + 1)) for _ in range(3)]
+            U = [rng.standard_normal((m, T)) for _ in range(3)]
+            alpha, new_step, new_fval, new_slope = rmpc.iqp_line_search(Q_ls, R_ls, X[0], U[0], X[1], U[1], X[2], U[2])
+            k = "ls_d%d_%s_" % (d, tag)
+            out[k + "Q"], out[k + "Qf"], out[k + "R"] = Q, Qf, R
+            out[k + "X"], out[k + "U"] = np.stack(X), np.stack(U)
+            out[k + "alpha"], out[k + "step"], out[k + "fval"], out[k + "slope"] = (np.array(alpha), np.array(new_step),
+                                                                                   np.array(new_fval), np.asarray(new_slope))
+
+    # ---- shift_guess, StepClock
+    g = rng.standard_normal((3, 5)) + 1j * rng.standard_normal((3, 5))
+    out["shift_in"], out["shift_out"] = g, rmpc.shift_guess(g)
+    ck = rmpc.StepClock(0.25, 7, 11)
+    ck.measure_freq = 3
+    out["clock_ts"], out["clock_ts_step5"], out["clock_ts_horizon4"] = ck.ts, ck.ts_step(5), ck.ts_horizon(4)
+    ck.set_endsim(6)
+    out["clock_ts_sim6"] = ck.ts_sim
+    out["clock_string"] = np.array(ck.to_string())
+
+    # ---- mpc()
+    log = []
+
+    class RecordingWrapModel(lin.WrapModel):
+        def get_model_along_traj(self, xs, us, ts):
+            log.append((float(ts[0]), np.array(xs, dtype=complex), np.array(us, dtype=float)))
+            return super().get_model_along_traj(xs, us, ts)
+    rmpc.WrapModel = RecordingWrapModel
+    names = []
+    for name, c in loop_cases().items():
+        d, m, dt, T, ns, order = c["d"], c["m"], c["dt"], c["T"], c["n_steps"], c["order"]
+        n = d * d
+        A_dst = vec.discretize_homogeneous([liou(H) for H in c["H_model"]], dt, order)
+        P = lin.size_of_library(order, m) - 1
+        model = mdl.DMDc(n, n, n * P, A_dst)
+        clock = rmpc.StepClock(dt, T, ns)
+        clock.measure_freq = c.get("measure_freq", 1)
+        plant = HeldPlant(c["H_plant"][0], c["H_plant"][1:], c.get("growth", 0.0))
+        cols = ns + T + 1
+        X_targ = np.tile(c["target"].reshape(-1, 1), (1, cols))
+        U_targ = np.zeros((m, cols))
+        Q = np.diag(np.array(c["Qdiag"], dtype=float))
+        R = c["R"] * np.identity(m)
+        x0 = c["x0"] * c.get("x0_scale", 1.0)
+        exit_condition = None
+        if "exit_index" in c:
+            ei, et = c["exit_index"], c["exit_thr"]
+            exit_condition = lambda xn, x, u: abs(xn[ei]) > et          # noqa: E731
+        del log[:]
+        k = "loop_" + name + "_"
+        names.append(name)
+        for key in ("d", "m", "dt", "T", "n_steps", "order", "sat", "du"):
+            out[k + key] = np.array(c[key])
+        out[k + "measure_freq"] = np.array(clock.measure_freq)
+        out[k + "warm_start"] = np.array(bool(c.get("warm_start", True)))
+        out[k + "max_iter"] = np.array(c.get("max_iter", 100))
+        out[k + "growth"] = np.array(c.get("growth", 0.0))
+        out[k + "exit_index"], out[k + "exit_thr"] = np.array(c.get("exit_index", -1)), np.array(c.get("exit_thr", 0.0))
+        out[k + "model"], out[k + "x0"] = A_dst, x0
+        out[k + "H_plant"] = np.stack(c["H_plant"])
+        out[k + "X_targ"], out[k + "U_targ"], out[k + "Q"], out[k + "R"] = X_targ, U_targ, Q, R
+        raised = ""
+        try:
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                (xs, us), _, code = rmpc.mpc(x0, m, order, X_targ, U_targ, clock, plant, model, Q, R, Q, sat=c["sat"],
+                                             du=c["du"], max_iter=c.get("max_iter", 100), exit_condition=exit_condition,
+                                             warm_start=c.get("warm_start", True), progress_bar=False)
+        except Exception as e:                                       # a NaN state: numpy.linalg.pinv raises inside lqr.py:61
+            raised = type(e).__name__
+            xs, us, code = np.zeros((n, 0)), None, -1
+        out[k + "raised"] = np.array(raised)
+        out[k + "xs"] = xs
+        out[k + "us"] = us if us is not None else np.zeros((m, 0))
+        out[k + "us_is_none"] = np.array(us is None)
+        out[k + "exit_code"] = np.array(code)
+        out[k + "ts_sim"] = np.asarray(clock.ts_sim)
+        out[k + "solve_step"] = np.array([int(round(t0 / dt)) for t0, _, _ in log], dtype=np.int32)
+        out[k + "solve_Xg"] = np.stack([xg for _, xg, _ in log]) if log else np.zeros((0, n, T + 1), dtype=complex)
+        out[k + "solve_Ug"] = np.stack([ug for _, _, ug in log]) if log else np.zeros((0, m, T))
+        print("%-24s exit_code %2d raised %-12s xs %s QP solves %d" % (name, code, raised or "-", xs.shape, len(log)))
+    out["loop_names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "mpc_loop.npz"), **out)
+    print("wrote mpc_loop.npz")
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["dmdc"]:
         golden_dmdc()
+    elif sys.argv[1:] == ["mpc_loop"]:
+        golden_mpc_loop()
     else:
         main()
         golden_dmdc()
+        golden_mpc_loop()

@@ -453,12 +453,14 @@ def test_exact_qp_session_rejects_ref_lqr():
 
 
 @pytest.mark.parametrize("path", ["real", "complex"])
-@pytest.mark.parametrize("cfg,order,batch,horizon", [(1, 2, 1, None), (3, 1, 4, None), (4, 1, 2, 12)])
+@pytest.mark.parametrize("cfg,order,batch,horizon", [(1, 1, 1, None), (1, 2, 1, None), (2, 1, 3, None), (3, 1, 4, None),
+                                                      (3, 2, 2, None), (4, 1, 2, 12), (4, 1, 2, None), (5, 1, 2, None)])
 def test_closed_loop_stepwise_teacher_forced(cfg, order, batch, horizon, path):
     """Every MPC step of the run, started from the ORACLE's state (states, controls, SQP guesses) through the
     session's checkpoint/restore fields.  The outputs of the step - applied control us[k], next state xs[k+1],
     QP-solve count - must match to 1e-10 whatever the conditioning of the loop; the shifted SQP
-    guesses (the far end of a stiff 40-step horizon) to 1e-7.  Config 3 runs at its own T = 40."""
+    guesses (the far end of a stiff 40-step horizon) to 1e-7.  horizon None = the BASELINE config's own size: every config
+    runs at its own T (config 2: 20, configs 3 and 4: 40, config 5: 80) for all of its 20 MPC steps."""
     p = configs.build(cfg, batch=max(batch, 4) if cfg == 3 else batch, order=order, horizon=horizon)
     idx = np.arange(batch)
     trace = []
@@ -872,10 +874,11 @@ def test_properties_at_scale(cfg, batch):
     assert res["qp_solves"][:, 2:].min() == 1 and res["qp_solves"][:, 2:].max() == 1
 
 
-@pytest.mark.parametrize("cfg,batch", [(3, 65536), (4, 8192)])
+@pytest.mark.parametrize("cfg,batch", [(3, 65536), (4, 8192), (5, 131072)])
 def test_properties_at_full_baseline_size(cfg, batch):
-    """BASELINE config 3 at its full single-GPU size (65,536 per-member models, T = 40) and config 4's per-GPU share of
-    the 8-way sharding, set up the way bench.py does (models built on the device from generators and per-member scales).
+    """BASELINE config 3 at its full single-GPU size (65,536 per-member models, T = 40), config 4's per-GPU share of
+    the 8-way sharding and config 5's (2^20 / 8 = 131,072 members, T = 80, all 20 MPC steps), set up the way bench.py
+    does (models built on the device from generators and per-member scales).
     The oracle cannot follow; every member must still finish with exit code 0, keep rho_t Hermitian with unit trace,
     respect the box and the du band, spend exactly one QP solve per warm step - and members with identical inputs placed
     in different wavefronts must produce identical bits."""
@@ -932,3 +935,196 @@ def test_repeated_launches_are_bit_identical(kw):
                     assert np.array_equal(res[key], first[key]), key
     finally:
         sess.close()
+
+
+# ---------------------------------------------------------------- the closed loop against the REFERENCE's own mpc.py
+# tests/golden/mpc_loop.npz: mpc4quantum/mpc.py:128-304 (loaded by path in the build container, tests/golden/make_golden.py)
+# around the reference's own lqr.quad_program; the fused kernel runs the same loop with M4Q_QP_REF_LQR.
+REF_LOOPS = ["qubit_o1", "qubit_o2_mf5", "qubit_o1_cold_cap4", "transmon_o1", "transmon_o2_mf2_cap5", "coupled_o1_cap6"]
+
+
+def _ref_case(g, name):
+    k = "loop_" + name + "_"
+    c = {key[len(k):]: g[key] for key in g.files if key.startswith(k)}
+    for key in ("d", "m", "T", "n_steps", "order", "measure_freq", "max_iter", "exit_index"):
+        c[key] = int(c[key])
+    for key in ("dt", "sat", "du", "growth", "exit_thr"):
+        c[key] = float(c[key])
+    c["warm_start"] = bool(c["warm_start"])
+    return c
+
+
+def _ref_plant(c):
+    """The golden scenario's plant as this package's experiment object."""
+    H = c["H_plant"]
+    if c["growth"]:
+        return m4q.LExperiment(m4q.liouvillian(H[0]) + c["growth"] * np.identity(c["d"] ** 2), [m4q.liouvillian(h) for h in H[1:]])
+    return m4q.QExperiment(H[0], list(H[1:]))
+
+
+def _ref_mpc(c, **kw):
+    n = c["d"] ** 2
+    clock = m4q.StepClock(c["dt"], c["T"], c["n_steps"])
+    clock.measure_freq = c["measure_freq"]
+    cond = None
+    if c["exit_index"] >= 0:
+        cond = lambda xn, x, u: abs(xn[c["exit_index"]]) > c["exit_thr"]      # noqa: E731
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        (xs, us), _, code = m4q.mpc(c["x0"], c["m"], c["order"], c["X_targ"], c["U_targ"], clock, _ref_plant(c),
+                                    m4q.DMDc(n, n, c["model"].shape[1] - n, c["model"]), c["Q"], c["R"], c["Q"], sat=c["sat"],
+                                    du=c["du"], max_iter=c["max_iter"], exit_condition=cond, warm_start=c["warm_start"],
+                                    progress_bar=False, qp_flags=_lib.QP_REF_LQR, **kw)
+    return xs, us, code, clock
+
+
+@pytest.mark.parametrize("path", ["real", "complex"])
+@pytest.mark.parametrize("name", REF_LOOPS)
+def test_mpc_loop_teacher_forced_vs_reference_mpc_py(golden, name, path):
+    """Every MPC step of the REFERENCE's run (its own mpc.py around its own lqr.py), restarted on the device from the
+    reference's state: states and controls so far and the SQP guess the reference handed to get_model_along_traj at the
+    first QP solve of the step.  The step's outputs us[k], xs[k+1] and its QP-solve count must match to 1e-10; the guess
+    the step leaves behind must be the one the reference starts step k+1 from.  Covers measure_freq in {1, 2, 5},
+    warm_start off, small max_iter, orders 1 and 2, d = 2, 3, 4."""
+    c = _ref_case(golden("mpc_loop"), name)
+    n, m, T, ns = c["d"] ** 2, c["m"], c["T"], c["n_steps"]
+    steps, Xg, Ug = c["solve_step"], c["solve_Xg"], c["solve_Ug"]
+    exp = _ref_plant(c)
+    op0, ops = exp.operators()
+    sess = m4q.EnsembleSession(1, n, m, c["order"], T, ns, c["dt"], c["sat"], c["du"], c["max_iter"], c["warm_start"],
+                               qp_flags=_lib.QP_REF_LQR, plant_kind=exp.plant_kind, target_cols=ns + T + 1,
+                               measure_freq=c["measure_freq"], force_complex=(path == "complex"))
+    try:
+        sess.load_problem(c["model"][None], c["x0"][None], c["X_targ"], c["U_targ"], c["Q"], c["R"], c["Q"], op0, ops)
+        assert sess.path() == path
+        xs_t, us_t = c["xs"].T[None], c["us"].T[None]
+        for k in range(ns):
+            idx = np.nonzero(steps == k)[0]
+            st = {"xs": np.zeros((1, ns + 1, n), dtype=complex), "us": np.zeros((1, ns, m)),
+                  "x_guess": Xg[idx[0]].T[None], "u_guess": Ug[idx[0]].T[None],
+                  "exit_codes": np.zeros(1, dtype=np.int32), "steps_done": np.full(1, k, dtype=np.int32)}
+            st["xs"][:, :k + 1] = xs_t[:, :k + 1]
+            st["us"][:, :k] = us_t[:, :k]
+            sess.restore(st)
+            sess.run(k, k + 1)
+            got = sess.state()
+            assert sess.download(_lib.F_QP_SOLVES, (1, ns))[0, k] == len(idx), k
+            assert rel(got["us"][:, k], us_t[:, k]) <= 1e-10, (k, rel(got["us"][:, k], us_t[:, k]))
+            assert rel(got["xs"][:, k + 1], xs_t[:, k + 1]) <= 1e-10, (k, rel(got["xs"][:, k + 1], xs_t[:, k + 1]))
+            if k + 1 < ns:
+                nxt = np.nonzero(steps == k + 1)[0][0]
+                assert rel(got["x_guess"][0], Xg[nxt].T) <= 1e-7 and rel(got["u_guess"][0], Ug[nxt].T) <= 1e-7, k
+    finally:
+        sess.close()
+
+
+@pytest.mark.parametrize("name", REF_LOOPS)
+def test_mpc_dropin_free_running_vs_reference_mpc_py(golden, name):
+    """The drop-in mpc() (one fused launch) against what the reference's mpc() returned: exit code, shapes, clock.ts_sim;
+    MPC steps 0 and 1 with all their SQP iterations to 1e-10, the rest of the free-running trajectory within the loop's
+    conditioning (the teacher-forced test above is the tight one)."""
+    c = _ref_case(golden("mpc_loop"), name)
+    xs, us, code, clock = _ref_mpc(c)
+    assert code == int(c["exit_code"]) == 0 and xs.shape == c["xs"].shape and us.shape == c["us"].shape
+    assert np.array_equal(clock.ts_sim, c["ts_sim"])
+    assert rel(us[:, :2], c["us"][:, :2]) <= 1e-10 and rel(xs[:, :3], c["xs"][:, :3]) <= 1e-10
+    assert rel(us, c["us"]) <= 1e-5 and rel(xs, c["xs"]) <= 1e-5
+
+
+@pytest.mark.parametrize("name", ["qubit_o1_exit_step3", "qubit_o1_exit_step0"])
+def test_mpc_dropin_exit_condition_vs_reference_mpc_py(golden, name):
+    """exit_condition firing mid-run and at step 0 (mpc.py:289-304): code 1, last attempted entry dropped, us None at step 0."""
+    c = _ref_case(golden("mpc_loop"), name)
+    xs, us, code, clock = _ref_mpc(c)
+    assert code == 1 == int(c["exit_code"]) and xs.shape == c["xs"].shape
+    assert rel(xs, c["xs"]) <= 1e-9
+    if bool(c["us_is_none"]):
+        assert us is None
+    else:
+        assert us.shape == c["us"].shape and rel(us, c["us"]) <= 1e-9
+    assert np.array_equal(clock.ts_sim, c["ts_sim"])
+
+
+def test_mpc_loop_nonfinite_vs_reference_mpc_py(golden):
+    """Exit code 3.  (a) An amplifying plant drives x^H Q x to overflow at MPC step 6: the reference returns code 3 with
+    7 states and 6 controls (mpc.py:200-203,298-304) and so does the fused kernel.  (b) DOCUMENTED DIFFERENCE: NaN (or 1e200)
+    in x0 makes the reference RAISE numpy.linalg.LinAlgError (pinv at lqr.py:61; mpc.py:200 tests isinf only); a batched
+    engine cannot raise for one ensemble member, it ends that member with code 3 at step 0 (states (n, 1), controls None)."""
+    g = golden("mpc_loop")
+    c = _ref_case(g, "qubit_o1_inf_later")
+    xs, us, code, clock = _ref_mpc(c)
+    assert code == 3 == int(c["exit_code"])
+    assert xs.shape == c["xs"].shape == (4, 7) and us.shape == c["us"].shape == (1, 6)
+    mask = np.abs(c["xs"]) > 0
+    assert np.abs(xs[mask] / c["xs"][mask] - 1).max() <= 1e-8 and rel(us[:, :2], c["us"][:, :2]) <= 1e-9
+    assert np.array_equal(clock.ts_sim, c["ts_sim"])
+    for name in ("qubit_o1_nan", "qubit_o1_inf_step0"):
+        c = _ref_case(g, name)
+        assert str(c["raised"]) == "LinAlgError"
+        xs, us, code, clock = _ref_mpc(c)
+        assert code == 3 and us is None and xs.shape == (4, 1) and len(clock.ts_sim) == 0
+
+
+def test_m4q_mpc_batch_entry_point_equals_session_path():
+    """The one-shot C entry point m4q_mpc_batch (include/m4q.h; SURVEY.md 8b's headline signature), called through ctypes
+    with caller-owned host buffers, against the session API on the same inputs: bit for bit."""
+    import ctypes as C
+    p = configs.build(3, batch=9, horizon=12, n_steps=6)           # 9 members: a ragged last quad
+    B, n, m, T, ns = 9, p["dim_x"], p["dim_u"], p["horizon"], p["n_steps"]
+    cols = ns + T + 1
+    sess = _session(p, B)
+    try:
+        sess.load_problem(p["models"], p["x0"], p["X_targ"], p["U_targ"], p["Q"], p["R"], p["Qf"], p["plant_op0"], p["plant_ops"])
+        sess.run(0, ns)
+        ref = sess.results()
+        prob = sess.problem
+    finally:
+        sess.close()
+    Xt = np.ascontiguousarray(np.asarray(p["X_targ"], dtype=np.complex128)[:, :cols].T)
+    Ut = np.zeros((cols, m))
+    Ut[:p["U_targ"].shape[1]] = np.real(p["U_targ"]).T[:cols]
+    xs = np.empty((B, ns + 1, n), dtype=np.complex128)
+    us = np.empty((B, ns, m))
+    codes = np.empty(B, dtype=np.int32)
+    done = np.empty(B, dtype=np.int32)
+    solves = np.empty((B, ns), dtype=np.int32)
+    keep = [_lib.cbuf(p["models"]), _lib.cbuf(p["x0"]), _lib.cbuf(Xt), _lib.rbuf(Ut), _lib.cbuf(p["Q"]), _lib.cbuf(p["R"]),
+            _lib.cbuf(p["Qf"]), _lib.cbuf(p["plant_op0"]), _lib.cbuf(p["plant_ops"])]
+    _lib.check(_lib.lib().m4q_mpc_batch(C.byref(prob), B, *[k[1] for k in keep], xs.ctypes.data_as(_lib._dp),
+                                        us.ctypes.data_as(_lib._dp), codes.ctypes.data_as(_lib._ip),
+                                        done.ctypes.data_as(_lib._ip), solves.ctypes.data_as(_lib._ip)))
+    assert np.array_equal(xs, ref["xs"]) and np.array_equal(us, ref["us"])
+    assert np.array_equal(codes, ref["exit_codes"]) and np.array_equal(done, ref["steps_done"])
+    assert np.array_equal(solves, ref["qp_solves"]) and np.all(codes == 0) and np.all(done == ns)
+    # bad arguments come back as error codes, not crashes
+    assert _lib.lib().m4q_mpc_batch(C.byref(prob), B, None, *[k[1] for k in keep[1:]], xs.ctypes.data_as(_lib._dp),
+                                    us.ctypes.data_as(_lib._dp), None, None, None) == _lib.E_BADARG
+
+
+def test_exact_qp_unconverged_solves_surface_as_exit_code_2():
+    """BASELINE config 5's horizon (T = 80) is beyond what the exact box-QP iteration resolves in fp64:
+    solves that stop at their iteration cap must not pass silently.  The reference's analogue is OSQP stopping at max_iter:
+    cvxpy warns, mpc.py:183-197 turns the warning into exit code 2 and ends the run.  Here the member ends with exit code 2 at
+    that step, the counters say how many solves ended that way, and mpc() warns."""
+    p = configs.build(5, batch=16)
+    res = _gpu_batch(p, np.arange(16), exact_qp=True)
+    n_solves, sweeps, ratio_steps, end_kkt, end_precision, end_cap = res["qp_stats"]
+    assert end_cap >= 1 and end_kkt + end_precision + end_cap == n_solves
+    assert int((res["exit_codes"] == 2).sum()) == end_cap                       # every capped solve ended its member's run
+    assert set(res["exit_codes"].tolist()) <= {0, 2}
+    capped = res["exit_codes"] == 2
+    assert np.all(res["steps_done"][capped] < p["n_steps"]) and np.all(res["steps_done"][~capped] == p["n_steps"])
+    # the same horizon with clipped solves (the default mode) runs through
+    clip = _gpu_batch(p, np.arange(16))
+    assert np.all(clip["exit_codes"] == 0)
+    # drop-in: warning + code 2 + trimmed returns
+    b = int(np.nonzero(capped)[0][0])
+    model = m4q.DMDc(9, 9, 18, p["models"][b])
+    clock = m4q.StepClock(p["dt"], p["horizon"], p["n_steps"])
+    with pytest.warns(UserWarning, match="iteration cap"):
+        (xs, us), _, code = m4q.mpc(p["x0"][b], 2, 1, p["X_targ"], p["U_targ"], clock,
+                                    m4q.QExperiment(p["plant_op0"][0], list(p["plant_ops"][0])), model, p["Q"], p["R"], p["Qf"],
+                                    sat=p["sat"], du=p["du"], progress_bar=False, exact_qp=True)
+    k = int(res["steps_done"][b])
+    assert code == 2 and xs.shape == (9, k + 1) and (us is None if k == 0 else us.shape == (2, k)) and len(clock.ts_sim) == k

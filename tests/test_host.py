@@ -97,6 +97,51 @@ def test_line_search_host_form_vs_oracle():
     assert abs(a1 - a2) < 1e-12 and abs(s1 - s2) < 1e-12
 
 
+@pytest.mark.parametrize("d", [2, 3, 4])
+@pytest.mark.parametrize("tag", ["diag", "dense"])
+def test_line_search_host_form_vs_reference_mpc_py(golden, d, tag):
+    """The package's host iqp_line_search against the reference's own (mpc.py:101-125): all four returns."""
+    g = golden("mpc_loop")
+    k = "ls_d%d_%s_" % (d, tag)
+    X, U = g[k + "X"], g[k + "U"]
+    T = U.shape[2]
+    Q_ls, R_ls = [g[k + "Q"]] * T + [g[k + "Qf"]], [g[k + "R"]] * T
+    alpha, step, fval, slope = m4q.iqp_line_search(Q_ls, R_ls, X[0], U[0], X[1], U[1], X[2], U[2])
+    for got, key in ((alpha, "alpha"), (step, "step"), (fval, "fval"), (slope, "slope")):
+        ref = g[k + key]
+        assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max()), key
+
+
+def test_clock_and_shift_guess_vs_reference_mpc_py(golden):
+    g = golden("mpc_loop")
+    assert np.array_equal(m4q.shift_guess(g["shift_in"]), g["shift_out"])
+    ck = m4q.StepClock(0.25, 7, 11)
+    ck.measure_freq = 3
+    assert np.array_equal(ck.ts, g["clock_ts"]) and np.array_equal(ck.ts_step(5), g["clock_ts_step5"])
+    assert np.array_equal(ck.ts_horizon(4), g["clock_ts_horizon4"])
+    ck.set_endsim(6)
+    assert np.array_equal(ck.ts_sim, g["clock_ts_sim6"])
+    assert ck.to_string() == str(g["clock_string"])
+
+
+@pytest.mark.parametrize("name,order", [("qubit", 1), ("qubit", 2), ("transmon", 1), ("transmon", 2), ("coupled", 1)])
+def test_wrapmodel_f_and_lift_u_vs_reference_golden(golden, name, order):
+    """Product WrapModel.f / lift_u / DMDc.predict (host NumPy, no GPU) against the reference's own outputs."""
+    g = golden("linearize")
+    key = "%s_o%d" % (name, order)
+    m = {"qubit": 1, "transmon": 2, "coupled": 3}[name]
+    model = g[key + "_model"]
+    n = model.shape[0]
+    dm = m4q.DMDc(n, n, model.shape[1] - n, model)
+    wm = m4q.WrapModel(*dm.get_discrete(), m, order)
+    xs, us = g[key + "_xs"], g[key + "_us"]
+    f = np.hstack([np.reshape(wm.f(xs[:, i], us[:, i], 0), (n, 1)) for i in range(us.shape[1])])
+    assert np.abs(f - g[key + "_f"]).max() <= 1e-13
+    assert np.abs(wm.lift_u(us) - g[key + "_liftu"]).max() <= 1e-13
+    ux = m4q.krtimes(wm.lift_u(us[:, :1]), xs[:, :1])
+    assert np.abs(dm.predict(xs[:, :1], ux) - g[key + "_predict"]).max() <= 1e-13
+
+
 def test_dmdc_container():
     A = np.arange(24).reshape(4, 6) + 1j
     d = m4q.DMDc(4, 4, 2, A)

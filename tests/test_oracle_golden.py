@@ -176,3 +176,139 @@ def test_exact_box_qp_oracle_satisfies_kkt():
     assert at_lo.sum() + at_hi.sum() > 3 and interior.sum() > 3
     assert np.abs(g[interior]).max() <= 1e-8 * scale
     assert np.all(g[at_lo] >= -1e-8 * scale) and np.all(g[at_hi] <= 1e-8 * scale)
+
+
+# ---------------------------------------------------------------- closed-loop driver, pinned against the reference's mpc.py
+# tests/golden/mpc_loop.npz: the reference's own mpc.py:101-125,128-304 run around its own lqr.quad_program (see
+# tests/golden/make_golden.py).  Pins rows a1 / a13 / a14 / a19 of SURVEY.md section 8.
+LOOPS_OK = ["qubit_o1", "qubit_o2_mf5", "qubit_o1_cold_cap4", "transmon_o1", "transmon_o2_mf2_cap5", "coupled_o1_cap6"]
+
+
+def loop_case(g, name):
+    k = "loop_" + name + "_"
+    c = {key[len(k):]: g[key] for key in g.files if key.startswith(k)}
+    for key in ("d", "m", "T", "n_steps", "order", "measure_freq", "max_iter", "exit_index"):
+        c[key] = int(c[key])
+    for key in ("dt", "sat", "du", "growth", "exit_thr"):
+        c[key] = float(c[key])
+    c["warm_start"] = bool(c["warm_start"])
+    return c
+
+
+def oracle_loop(c, **kw):
+    """The oracle's loop (qp_mode "lqr" = the arithmetic of lqr.py) on a golden scenario."""
+    n = c["d"] ** 2
+    model = orc.OracleDMDc(n, n, c["model"].shape[1] - n, c["model"])
+    clock = orc.OracleClock(c["dt"], c["T"], c["n_steps"])
+    clock.measure_freq = c["measure_freq"]
+    H = c["H_plant"]
+    if c["growth"]:
+        exp = orc.OracleLExperiment(orc.liouvillian_ij(H[0]) + c["growth"] * np.identity(n),
+                                    [orc.liouvillian_ij(h) for h in H[1:]])
+    else:
+        exp = orc.OracleQExperiment(H[0], list(H[1:]))
+    cond = None
+    if c["exit_index"] >= 0:
+        cond = lambda xn, x, u: abs(xn[c["exit_index"]]) > c["exit_thr"]      # noqa: E731
+    (xs, us), _, code = orc.mpc(c["x0"], c["m"], c["order"], c["X_targ"], c["U_targ"], clock, exp, model, c["Q"], c["R"],
+                                c["Q"], sat=c["sat"], du=c["du"], max_iter=c["max_iter"], exit_condition=cond,
+                                warm_start=c["warm_start"], qp_mode="lqr", **kw)
+    return xs, us, code, clock
+
+
+@pytest.mark.parametrize("d", [2, 3, 4])
+@pytest.mark.parametrize("tag", ["diag", "dense"])
+def test_iqp_line_search_vs_reference_mpc_py(golden, d, tag):
+    g = golden("mpc_loop")
+    k = "ls_d%d_%s_" % (d, tag)
+    X, U = g[k + "X"], g[k + "U"]
+    T = U.shape[2]
+    Q_ls, R_ls = [g[k + "Q"]] * T + [g[k + "Qf"]], [g[k + "R"]] * T
+    alpha, step = orc.iqp_line_search(Q_ls, R_ls, X[0], U[0], X[1], U[1], X[2], U[2])
+    assert abs(alpha - float(g[k + "alpha"])) <= TOL * max(1.0, abs(float(g[k + "alpha"])))
+    assert abs(step - float(g[k + "step"])) <= TOL * max(1.0, float(g[k + "step"]))
+
+
+def test_shift_guess_and_clock_vs_reference_mpc_py(golden):
+    g = golden("mpc_loop")
+    assert np.array_equal(orc.shift_guess(g["shift_in"]), g["shift_out"])
+    ck = orc.OracleClock(0.25, 7, 11)
+    ck.measure_freq = 3
+    assert np.array_equal(ck.ts, g["clock_ts"]) and np.array_equal(ck.ts_step(5), g["clock_ts_step5"])
+    assert np.array_equal(ck.ts_horizon(4), g["clock_ts_horizon4"])
+    ck.set_endsim(6)
+    assert np.array_equal(ck.ts_sim, g["clock_ts_sim6"])
+
+
+@pytest.mark.parametrize("name", LOOPS_OK)
+def test_mpc_loop_teacher_forced_vs_reference_mpc_py(golden, name):
+    """Every MPC step of the reference's run, restarted from the REFERENCE's state (xs, us, SQP guess at the first QP
+    solve of the step): the oracle must make the same number of QP solves with the same SQP iterates and produce the same
+    us[k], xs[k+1].  Step by step the comparison is not polluted by the conditioning of the free-running loop."""
+    c = loop_case(golden("mpc_loop"), name)
+    steps, Xg, Ug = c["solve_step"], c["solve_Xg"], c["solve_Ug"]
+    assert int(c["exit_code"]) == 0
+    for k in range(c["n_steps"]):
+        idx = np.nonzero(steps == k)[0]
+        st = dict(step=k, xs=c["xs"], us=c["us"], X_guess=Xg[idx[0]], U_guess=Ug[idx[0]])
+        tr = []
+        xs, us, code, _ = oracle_loop(c, start=st, stop=k + 1, solve_trace=tr)
+        assert code == 0 and len(tr) == len(idx), (k, len(tr), len(idx))
+        for (s_k, X, U), i in zip(tr, idx):
+            assert s_k == k
+            assert np.abs(X - Xg[i]).max() <= 1e-10 and np.abs(U - Ug[i]).max() <= 1e-10, (k, i)
+        assert np.abs(us[:, k] - c["us"][:, k]).max() <= 1e-11, (k, np.abs(us[:, k] - c["us"][:, k]).max())
+        assert np.abs(xs[:, k + 1] - c["xs"][:, k + 1]).max() <= 1e-11, k
+
+
+@pytest.mark.parametrize("name", LOOPS_OK)
+def test_mpc_loop_free_running_vs_reference_mpc_py(golden, name):
+    """The whole run: same exit code, same returned shapes, same clock.ts_sim, same QP-solve schedule.  Steps 0 and 1
+    (all their SQP iterations) to 1e-10; later steps within what the loop's conditioning allows (controls saturate, so
+    differences in the last bits of a bang-bang switch grow) - bounded loosely here, tightly by the teacher-forced test."""
+    c = loop_case(golden("mpc_loop"), name)
+    tr = []
+    xs, us, code, clock = oracle_loop(c, solve_trace=tr)
+    assert code == int(c["exit_code"]) and xs.shape == c["xs"].shape and us.shape == c["us"].shape
+    assert np.array_equal(clock.ts_sim, c["ts_sim"])
+    assert np.array_equal(np.array([s for s, _, _ in tr]), c["solve_step"])
+    assert np.abs(us[:, :2] - c["us"][:, :2]).max() <= 1e-10 and np.abs(xs[:, :3] - c["xs"][:, :3]).max() <= 1e-10
+    assert np.abs(us - c["us"]).max() <= 1e-6 * c["sat"] and np.abs(xs - c["xs"]).max() <= 1e-6
+
+
+@pytest.mark.parametrize("name", ["qubit_o1_exit_step3", "qubit_o1_exit_step0"])
+def test_mpc_loop_exit_condition_vs_reference_mpc_py(golden, name):
+    """exit_condition firing (code 1) mid-run and at step 0: the last attempted entry is dropped, controls are None at
+    step 0, clock.set_endsim(step) (mpc.py:289-304)."""
+    c = loop_case(golden("mpc_loop"), name)
+    xs, us, code, clock = oracle_loop(c)
+    assert code == 1 == int(c["exit_code"])
+    assert xs.shape == c["xs"].shape and np.abs(xs - c["xs"]).max() <= 1e-10
+    if bool(c["us_is_none"]):
+        assert us is None
+    else:
+        assert us.shape == c["us"].shape and np.abs(us - c["us"]).max() <= 1e-10
+    assert np.array_equal(clock.ts_sim, c["ts_sim"])
+
+
+def test_mpc_loop_infinite_objective_vs_reference_mpc_py(golden):
+    """Exit code 3 (mpc.py:200-203): a plant that amplifies the state until x^H Q x overflows at MPC step 6."""
+    c = loop_case(golden("mpc_loop"), "qubit_o1_inf_later")
+    xs, us, code, clock = oracle_loop(c)
+    assert code == 3 == int(c["exit_code"])
+    assert xs.shape == c["xs"].shape == (4, 7) and us.shape == c["us"].shape
+    assert np.abs(xs / c["xs"] - 1)[np.abs(c["xs"]) > 0].max() <= 1e-9
+    assert np.array_equal(clock.ts_sim, c["ts_sim"])
+
+
+def test_mpc_loop_nan_raises_like_the_reference(golden):
+    """NaN (or 1e200) in x0: the reference does not return exit code 3 - mpc.py:200 tests np.isinf only, a NaN objective
+    passes, and numpy.linalg.pinv raises LinAlgError at lqr.py:61 (1e200: at the first solve, B^H V B overflows).  The
+    oracle follows.  The batched HIP engine cannot raise for one ensemble member: it ends that member with exit code 3
+    (tests/test_gpu_parity.py::test_mpc_loop_nonfinite_vs_reference_mpc_py, DESIGN.md section 2)."""
+    g = golden("mpc_loop")
+    for name in ("qubit_o1_nan", "qubit_o1_inf_step0"):
+        c = loop_case(g, name)
+        assert str(c["raised"]) == "LinAlgError" and int(c["exit_code"]) == -1
+        with pytest.raises(np.linalg.LinAlgError):
+            oracle_loop(c)
