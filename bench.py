@@ -22,16 +22,51 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# algorithmic work per horizon-step (SURVEY.md 8d / BASELINE.md 4), order 1
+# algorithmic work per horizon-step (SURVEY.md 8d / BASELINE.md 4), order 1: the COMPLEX recursion of lqr.py (complex MAC = 8 flop)
 ALG_FLOP = {4: 3.5e3, 9: 27e3, 16: 126e3}
-PEAK_F64_TFLOPS = 78.6      # MI355X fp64 vector == fp64 matrix dense rate (AMD spec; 256 CU x 4 SIMD x 16 FMA lanes x 2.4 GHz;
-                            # tools/ubench_dpp.hip measures 78.0 with v_fmac_f64_dpp)
+PEAK_F64_TFLOPS = 78.6      # MI355X fp64 dense rate (AMD spec; 256 CU x 4 SIMD x 16 FMA lanes x 2.4 GHz).  v_fma_f64 (used here, with
+                            # DPP row broadcasts) and v_mfma_f64 run on the SAME pipe at the same rate: tools/ubench_mfma.hip measures
+                            # 76-78 TFLOP/s for either and the SUM when both are issued (profiles/r02_ubench_mfma.txt)
 PEAK_HBM_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md
+PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc.json")
 
 
-def alg_bytes_per_hstep(n, m, P, T):
-    """model + X_guess in + U_guess in + X_opt, U_opt out, per QP solve, divided by T."""
-    return (16 * n * n * (1 + P) + 16 * n * (T + 1) + 8 * m * T + 16 * n * (T + 1) + 8 * m * T) / T
+def executed_flop_per_hstep(n, path):
+    """Arithmetic the selected path executes per horizon-step: the real (Hermitian-basis) path runs the same recursion on
+    real numbers, a quarter of the real flops of the complex one."""
+    return ALG_FLOP[n] / (4.0 if path == "real" else 1.0)
+
+
+def compulsory_bytes(B, n, m, P, T, ns, path):
+    """HBM bytes a persistent launch cannot avoid (model and guess terms counted once per run, not per solve):
+    per member, the model and initial state in, xs / us / SQP-guess checkpoint / codes / solve counts out."""
+    sz = 8 if path == "real" else 16
+    per = sz * n * n * (1 + P) + (16 + sz) * n + 16 * n * (ns + 1) + 8 * m * ns + 16 * n * (T + 1) + 8 * m * T + 8 + 4 * ns
+    return B * per
+
+
+def pmc_record(key, avg_launch_ms):
+    """Counter record of this exact configuration from profiles/r02_pmc.json (tools/pmc_collect.py), or (None, why).  Refused when
+    the launch it was taken on differs from the one measured now by more than 3 %: counters describe a binary, not a config."""
+    try:
+        rec = json.load(open(PMC_JSON))[key]
+    except Exception:
+        return None, "no counter record for %s in profiles/r02_pmc.json" % key
+    ref = rec.get("traced_avg_launch_ms") or 0.0
+    if not ref or abs(avg_launch_ms - ref) > 0.03 * ref:
+        return None, "counter record for %s was taken at %.2f ms per launch, this run measures %.2f ms: stale, not reported" % (
+            key, ref, avg_launch_ms)
+    return rec, None
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def _cpu_worker(config, lo, hi, budget):
@@ -83,7 +118,8 @@ def cpu_baseline(config, p, cores, seconds_budget=20.0, members_per_core=64):
     units = sum(r["units"] for r in results)
     wall = max(r["seconds"] for r in results)
     return {"value": units / wall, "unit": "MPC horizon-steps/s", "cores": len(results), "kind": "port",
-            "per_core": units / sum(r["seconds"] for r in results),
+            "per_core": units / sum(r["seconds"] for r in results), "cpu": cpu_model(),
+            "host_cores_available": len(os.sched_getaffinity(0)),
             "sample": "%d of %d ensemble members (%d processes x ~%.0f s, one core each), full closed loop (n_steps=%d, T=%d), "
                       "NumPy oracle" % (sum(r["members"] for r in results), p["x0"].shape[0], len(results), wall, p["n_steps"],
                                         p["horizon"])}
@@ -99,8 +135,7 @@ def main():
     ap.add_argument("--config", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="ensemble members per GPU (default: the config's own size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-cores", type=int, default=0, help="host cores for the CPU baseline (0 = all this process may use, "
-                                                             "at most 16)")
+    ap.add_argument("--cpu-cores", type=int, default=0, help="host cores for the CPU baseline (0 = all this process may use)")
     ap.add_argument("--backend", default="nccl", help="collective backend for N > 1: nccl (= RCCL over xGMI, the real thing) or "
                                                       "gloo (rehearsal on a box with fewer GPUs than ranks: results staged through the host)")
     ap.add_argument("--exact-qp", action="store_true", help="not the headline: every QP solved to the box-constrained optimum "
@@ -141,15 +176,12 @@ def main():
 
     sess = EnsembleSession(B, n, m, p["order"], T, ns, p["dt"], p["sat"], p["du"], model_per_instance=per_model,
                            target_cols=ns + T + 1, device=dev_index if multi else -1, exact_qp=args.exact_qp)
-    gather_bufs = None
+    shard = None
     if multi:
-        # results live in torch-owned HBM so RCCL can gather them without a copy
-        us_t = torch.empty(B * ns * m, dtype=torch.float64, device="cuda")
-        xs_t = torch.empty(B * (ns + 1) * n * 2, dtype=torch.float64, device="cuda")
-        sess.bind_output(_lib.F_US, us_t.data_ptr(), us_t.numel() * 8)
-        sess.bind_output(_lib.F_XS, xs_t.data_ptr(), xs_t.numel() * 8)
-        us_all = torch.empty(world * us_t.numel(), dtype=torch.float64, device="cuda") if rank == 0 else None
-        gather_bufs = (us_t, us_all)
+        # the product's multi-GPU path (mpc4quantum_amd/distributed.py): the session's outputs are bound into ONE torch-owned
+        # device buffer [final states | us | codes | steps done | solve counts] and one RCCL gather moves it
+        from mpc4quantum_amd.distributed import ShardedResults
+        shard = ShardedResults(sess, B, dst=0, final_state_only=True)
     if per_model:
         sess.build_models(p["dt"], p["generators"], p["scales"])
         models = None
@@ -161,20 +193,7 @@ def main():
     def one_step():
         sess.run(0, ns)
         if multi:
-            sess.sync()
-            us_t, us_all = gather_bufs
-            xs_final = xs_t.view(B, ns + 1, n * 2)[:, -1, :].contiguous()
-            if args.backend != "nccl":                             # rehearsal: gloo moves host tensors
-                xs_final, us_src = xs_final.cpu(), us_t.cpu()
-                outs = [torch.empty_like(xs_final) for _ in range(world)] if rank == 0 else None
-                dist.gather(xs_final, outs, dst=0)
-                chunks = [torch.empty_like(us_src) for _ in range(world)] if rank == 0 else None
-                dist.gather(us_src, chunks, dst=0)
-                return
-            outs = [torch.empty_like(xs_final) for _ in range(world)] if rank == 0 else None
-            dist.gather(xs_final, outs, dst=0)                     # the one RCCL collective of the job
-            chunks = list(us_all.chunk(world)) if rank == 0 else None
-            dist.gather(us_t, chunks, dst=0)
+            shard.gather()                                         # the one collective of the job
 
     def fence():
         sess.sync()
@@ -214,19 +233,28 @@ def main():
     if rank == 0:
         value = units_total * args.steps / elapsed
         avg_launch_s = kern_ms / max(launches, 1) / 1e3
-        flops = ALG_FLOP[n] * units_per_step
         qp_stats = sess.qp_stats() if args.exact_qp else None
-        if qp_stats:
-            # one pinned sweep + policy rollout over the horizon is the arithmetic of one clipped solve
-            flops = ALG_FLOP[n] * T * qp_stats[1]
-        abytes = alg_bytes_per_hstep(n, m, P, T) * units_per_step
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf)).get("config%d_B%d_%s" % (args.config, B, path))
-            except Exception:
-                traffic = None
+        # units of arithmetic per launch: horizon-steps; in the exact mode one pinned sweep + policy rollout over the horizon
+        # is the arithmetic of one clipped solve
+        hsteps = T * qp_stats[1] if qp_stats else units_per_step
+        flops_exec = executed_flop_per_hstep(n, path) * hsteps
+        flops_alg = ALG_FLOP[n] * hsteps
+        cbytes = compulsory_bytes(B, n, m, P, T, ns, path)
+        key = "config%d_B%d_%s_%s" % (args.config, B, path, "exact" if args.exact_qp else "clip")
+        rec, why = pmc_record(key, 1e3 * avg_launch_s)
+        traffic = issue = None
+        if rec:
+            c = rec["counters"]
+            # FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE counts 64 B per 128-B request for this kernel's 8-16 B per
+            # lane row accesses as for wide streaming reads (tools/ubench_fetch.hip, profiles/r02_fetch_calibration.txt)
+            if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                traffic = (rec.get("fetch_factor", 2.0) * c["FETCH_SIZE"] + rec.get("write_factor", 1.0) * c["WRITE_SIZE"]) * 1024.0
+            if "SQ_INSTS_VALU_FMA_F64" in c:
+                slots = 1024 * (rec["traced_avg_launch_ms"] * 1e-3 * 2.4e9) / 4.0      # fp64 FMA wave-instruction slots of the chip
+                issue = {"fma_f64_wave_insts": c["SQ_INSTS_VALU_FMA_F64"], "frac_of_fma_issue_slots": c["SQ_INSTS_VALU_FMA_F64"] / slots,
+                         "valu_busy": c.get("SQ_ACTIVE_INST_VALU", 0) / slots if "SQ_ACTIVE_INST_VALU" in c else None,
+                         "wave_time_waiting": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"] if "SQ_WAVE_CYCLES" in c else None,
+                         "note": "all 64 lanes counted; at 2.4 GHz (the chip clocks lower under this load)"}
         out = {
             "metric": "MPC horizon-steps/sec across batch (3-level transmon, T=40)" if args.config == 3
                       else "MPC horizon-steps/sec across batch (config %d)" % args.config,
@@ -241,19 +269,28 @@ def main():
                        **({"qp_mode": "exact box-constrained (active set on the Riccati factorisation)",
                            "exact_qp_stats": dict(zip(("qp_solves", "pinned_sweeps", "ratio_steps", "end_kkt", "end_precision",
                                                        "end_cap"), qp_stats))} if qp_stats else {})},
-            "roofline": {"bound": "mfma", "achieved": flops / avg_launch_s / 1e12, "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s",
-                         "frac": flops / avg_launch_s / 1e12 / PEAK_F64_TFLOPS, "traffic": traffic,
+            "roofline": {"bound": "valu_f64", "achieved": flops_exec / avg_launch_s / 1e12, "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flops_exec / avg_launch_s / 1e12 / PEAK_F64_TFLOPS, "traffic": traffic,
                          "kernel": "mpc_kernel<%s, PLANT_HAMILTONIAN, %s>" % ("double" if path == "real" else "cplx",
-                                                                              "true" if args.exact_qp else "false"), "launches": launches, "avg_launch_ms": 1e3 * avg_launch_s,
-                         "note": "fp64 compute roof: v_fma_f64 (VALU, used here with DPP row broadcasts) and v_mfma_f64 share the "
-                                 "78.6 TFLOP/s dense rate on MI355X; achieved = ALGORITHMIC flops (SURVEY 8d, complex recursion) / launch time. "
-                                 "The real path executes a quarter of them: its executed-FMA issue rate is 47% of peak, the complex path's 72% "
-                                 "(PMC, DESIGN.md section 5)",
-                         "hbm": {"achieved": abytes / avg_launch_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                 "frac": abytes / avg_launch_s / 1e9 / PEAK_HBM_GBS}},
+                                                                              "true" if args.exact_qp else "false"),
+                         "launches": launches, "avg_launch_ms": 1e3 * avg_launch_s,
+                         "flop_per_horizon_step": executed_flop_per_hstep(n, path), "horizon_steps_per_launch": hsteps,
+                         "note": "compute-bound kernel: intensity >> the fp64 machine balance, so the binding roof is fp64 FMA issue "
+                                 "(v_fma_f64 with DPP row broadcasts; no MFMA instruction is executed - fp64 MFMA shares this pipe and "
+                                 "peak).  achieved = flops of the arithmetic the selected path EXECUTES (real path: a quarter of SURVEY "
+                                 "8d's complex-recursion count) / HIP-event launch time",
+                         "algorithmic_equivalent": {"achieved": flops_alg / avg_launch_s / 1e12, "unit": "TFLOP/s",
+                                                    "note": "SURVEY 8d complex-recursion flops / time: a speed-up-adjusted throughput, "
+                                                            "NOT a fraction of any roof (exceeds the peak on the real path at d=4)"},
+                         "issue": issue,
+                         "hbm": {"achieved": cbytes / avg_launch_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "frac": cbytes / avg_launch_s / 1e9 / PEAK_HBM_GBS, "compulsory_bytes": cbytes,
+                                 "note": "compulsory bytes of the persistent launch (models, states and guesses once per run)"},
+                         "traffic_note": why or "FETCH_SIZE/WRITE_SIZE of profiles/r02_pmc.json, taken on this binary (launch time "
+                                                "within 3 %): L2-miss bytes per launch, mostly served by the Infinity Cache"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            cores = args.cpu_cores or min(16, len(os.sched_getaffinity(0)))
+            cores = args.cpu_cores or len(os.sched_getaffinity(0))
             out["cpu_baseline"] = cpu_baseline(args.config, p, cores)
         print(json.dumps(out))
     sess.close()

@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libm4q_hip.so")
+# M4Q_LIB: an experiment build of the same library (tools/build_variant.sh) - still the HIP library, never a CPU path
+LIB_PATH = os.path.abspath(os.environ["M4Q_LIB"]) if os.environ.get("M4Q_LIB") else os.path.join(_HERE, "libm4q_hip.so")
 
 QP_REF_LQR = 1
 QP_DU_BAND = 2

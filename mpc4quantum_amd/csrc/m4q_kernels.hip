@@ -128,18 +128,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
   cost.Q = ldsQ; cost.Qf = ldsQ + NX * NX; cost.q_stride = 0; cost.R = ldsQ + 2 * NX * NX; cost.r_stride = 0;
   // workspace of this resident row: wave-uniform base per workgroup, lane part = row within the wave
   const unsigned sX = (unsigned)(T + 1) * NX, sU = (unsigned)T * NU, sG = (unsigned)T * (NX + 1) * NU;
-  const GView Xg = gview(static_cast<S*>(a.ws_Xg), (long)blockIdx.x * ROWS * sX, g * sX);
-  const GView Ug = gview(a.ws_Ug, (long)blockIdx.x * ROWS * sU, g * sU);
+#ifndef M4Q_EXP
+#define M4Q_EXP 0
+#endif
+  // (timing-only ablations, results wrong: M4Q_EXP & 64 - every workgroup uses workgroup 0's gain workspace, & 128 - and its
+  //  trajectory workspace: what the launch would take if those bytes came from the L2 instead of the Infinity Cache / HBM)
+  const long wsb = (M4Q_EXP & 128) ? 0 : (long)blockIdx.x, wsg = (M4Q_EXP & 64) ? 0 : (long)blockIdx.x;
+  const GView Xg = gview(static_cast<S*>(a.ws_Xg), wsb * ROWS * sX, g * sX);
+  const GView Ug = gview(a.ws_Ug, wsb * ROWS * sU, g * sU);
   // (Xo, Uo) live in the same allocations right behind all the (Xg, Ug): same wave-uniform base, so a row can
   // direct its rollout output to either by its lane offset alone
-  const GView Xo = gview(static_cast<S*>(a.ws_Xg), (long)blockIdx.x * ROWS * sX, g * sX + gridDim.x * ROWS * sX);
-  const GView Uo = gview(a.ws_Ug, (long)blockIdx.x * ROWS * sU, g * sU + gridDim.x * ROWS * sU);
-  const GView gains = gview(static_cast<S*>(a.ws_gains), (long)blockIdx.x * ROWS * sG, g * sG);
+  const GView Xo = gview(static_cast<S*>(a.ws_Xg), wsb * ROWS * sX, g * sX + gridDim.x * ROWS * sX);
+  const GView Uo = gview(a.ws_Ug, wsb * ROWS * sU, g * sU + gridDim.x * ROWS * sU);
+  const GView gains = gview(static_cast<S*>(a.ws_gains), wsg * ROWS * sG, g * sG);
   // EXACT (M4Q_QP_EXACT_BOX): third trajectory pair, working set and Newton point of the projected-Newton solver,
   // again behind the others in the same allocations
-  const GView Xalt = gview(static_cast<S*>(a.ws_Xg), (long)blockIdx.x * ROWS * sX, g * sX + 2 * gridDim.x * ROWS * sX);
-  const GView Ualt = gview(a.ws_Ug, (long)blockIdx.x * ROWS * sU, g * sU + 2 * gridDim.x * ROWS * sU);
-  const GView pin_stat = gview(a.ws_Ug, (long)blockIdx.x * ROWS * sU, g * sU + 3 * gridDim.x * ROWS * sU);
+  const GView Xalt = gview(static_cast<S*>(a.ws_Xg), wsb * ROWS * sX, g * sX + 2 * gridDim.x * ROWS * sX);
+  const GView Ualt = gview(a.ws_Ug, wsb * ROWS * sU, g * sU + 2 * gridDim.x * ROWS * sU);
+  const GView pin_stat = gview(a.ws_Ug, wsb * ROWS * sU, g * sU + 3 * gridDim.x * ROWS * sU);
   FusedProv<S, NX, NU, ORDER> prov;
   prov.mdl = mdl; prov.Xg = Xg; prov.Ug = Ug; prov.j = j;
   const long sXs = (long)(a.n_steps + 1) * NX, sUs = (long)a.n_steps * NU;
@@ -272,9 +278,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
     }
     const bool use_ls = !(a.warm_start && step > 1);        // mpc.py:208-213
     const bool st = running && lane_ok;
-#ifndef M4Q_EXP
-#define M4Q_EXP 0
-#endif
     // M4Q_EXP: timing-only ablation builds (results are wrong): 1 fixed 3 SQP iterations, 2 no backward,
     // 4 no forward, 8 no line search, 16 no guess update, 32 no plant/shift
     if constexpr (!EXACT && !(M4Q_EXP & 2)) riccati_backward<S, NX, NU>(prov, T, win, cost, a.flags, gains, j, st);
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
     wave_sync();
     // exit code 3: non-finite objective (mpc.py:200-203).  exit code 2 (EXACT only): the solver gave up - the analogue of
     // the solver warning mpc.py:183-197 turns into code 2; either way the member's run ends here (mpc.py:196,203,231).
-    const bool fail = !finite_d(chk) || capped;
+    const bool fail = (M4Q_EXP & (64 | 128)) ? false : (!finite_d(chk) || capped);
     if (solved) ++iter;
     double alpha = 1.0;
     bool fin = true;

@@ -168,8 +168,51 @@ template <> struct BasisIO<double> {
 // A_t.  rows(): for the row this lane owns, (A_t v)_j for a distributed vector v, row j of B_t and
 // Delta_t[j].  Views are positioned on this lane's instance; lane-dependent parts are 32-bit offsets.
 // ---------------------------------------------------------------------------------------------
+// one model element from LDS.  (M4Q_EXP & 256: timing-only ablation, results wrong - an opaque register copy instead of
+// the LDS read: what the launch would take without any LDS traffic or latency for the model)
+#ifndef M4Q_EXP
+#define M4Q_EXP 0
+#endif
+template <class S>
+__device__ __forceinline__ S mld(const S* mdl, int idx) {
+  if constexpr ((M4Q_EXP & 256) != 0) {
+    double v = 1e-3 * (double)(idx & 7);
+    asm volatile("" : "+v"(v));
+    return from_real<S>(v);
+  } else {
+    return mdl[idx];
+  }
+}
+
+// Real path, backward sweep: the column form (for A_t's column) and the row form (for A_t xbar and row j of B_t) of the model
+// are read from LDS in ONE batch at the top of the horizon index - at that point only P and the prefetched operands are live,
+// so the 2 (1 + NP) NX doubles fit - instead of in small groups each followed by its own wait: a wavefront alone on its SIMD
+// spent a quarter of every horizon index in a dozen serialised LDS read-to-use latencies (profiles/README.md).
+template <class S, int NX, int NU, int ORDER>
+struct ModelRegs {
+  static constexpr int NP = PowTab<NU, ORDER>::NP;
+  S col[1 + NP][NX];     // col[p][i] = block p, element [i][j]
+  S row[1 + NP][NX];     // row[p][k] = block p, element [j][k]
+  __device__ __forceinline__ void load(const S* mdl, int j) {
+#pragma unroll
+    for (int p = 0; p <= NP; ++p) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) col[p][i] = mld(mdl, ModelPitch<NX>::at(p, i, j));
+    }
+    load_rows(mdl, j);
+  }
+  __device__ __forceinline__ void load_rows(const S* mdl, int j) {
+#pragma unroll
+    for (int p = 0; p <= NP; ++p) {
+#pragma unroll
+      for (int k = 0; k < NX; ++k) row[p][k] = mld(mdl, ModelPitch<NX>::at(p, j, k));
+    }
+  }
+};
+
 template <class S, int NX, int NU, int ORDER>
 struct FusedProv {
+  static constexpr int ORDER_ = ORDER;
   static constexpr int NP = PowTab<NU, ORDER>::NP;
   static constexpr int PITCH = ModelPitch<NX>::value;
   const S* mdl;       // LDS, [1+NP][NX][PITCH]: block 0 = A, block 1+p = N_p   (model.py:95-103)
@@ -194,10 +237,65 @@ struct FusedProv {
     po.eval(l.u);
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      S a = mdl[ModelPitch<NX>::at(0, i, j)];
+      S a = mld(mdl, ModelPitch<NX>::at(0, i, j));
 #pragma unroll
-      for (int p = 0; p < NP; ++p) cmac_r(a, mdl[ModelPitch<NX>::at(1 + p, i, j)], po.pu[p]);
+      for (int p = 0; p < NP; ++p) cmac_r(a, mld(mdl, ModelPitch<NX>::at(1 + p, i, j)), po.pu[p]);
       Ac[i] = a;
+    }
+  }
+  // col() and rows() from registers loaded in one batch (real path of the backward sweep)
+  __device__ __forceinline__ void col_rows(const Lin& l, S v, S (&Ac)[NX], S& av, S (&Brow)[NU], S& dlt) const {
+    ModelRegs<S, NX, NU, ORDER> r;
+    r.load(mdl, j);
+    __builtin_amdgcn_sched_barrier(0);
+    col_rows(r, l, v, Ac, av, Brow, dlt);
+  }
+  // ... from registers the caller holds (n = 16 at one wavefront per SIMD: the whole model stays in registers over a sweep)
+  __device__ __forceinline__ void col_rows(const ModelRegs<S, NX, NU, ORDER>& r, const Lin& l, S v, S (&Ac)[NX], S& av, S (&Brow)[NU],
+                                           S& dlt) const {
+    Poly<NU, ORDER> po;
+    po.eval(l.u);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      S a = r.col[0][i];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) cmac_r(a, r.col[1 + p][i], po.pu[p]);
+      Ac[i] = a;
+    }
+    rows_from(r, l, po, v, av, Brow, dlt);
+  }
+  __device__ __forceinline__ void rows_from(const ModelRegs<S, NX, NU, ORDER>& r, const Lin& l, const Poly<NU, ORDER>& po, S v, S& av,
+                                            S (&Brow)[NU], S& dlt) const {
+    S nx[NP], arow[NX];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) arow[k] = r.row[0][k];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+#pragma unroll
+      for (int k = 0; k < NX; ++k) cmac_r(arow[k], r.row[1 + p][k], po.pu[p]);
+      nx[p] = dot_lane_index<false, false, NX>(l.xg, r.row[1 + p]);
+    }
+    av = dot_lane_index<false, false, NX>(v, arow);
+    finish_rows(l, po, nx, Brow, dlt);
+  }
+  __device__ __forceinline__ void rows(const ModelRegs<S, NX, NU, ORDER>& r, const Lin& l, S v, S& av, S (&Brow)[NU], S& dlt) const {
+    Poly<NU, ORDER> po;
+    po.eval(l.u);
+    rows_from(r, l, po, v, av, Brow, dlt);
+  }
+  __device__ __forceinline__ void finish_rows(const Lin& l, const Poly<NU, ORDER>& po, const S (&nx)[NP], S (&Brow)[NU], S& dlt) const {
+    dlt = zero_of<S>();
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+      S b = zero_of<S>();
+      if constexpr (ORDER == 1) {
+        b = nx[k];
+      } else {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) cmac_r(b, nx[p], po.dpu[k][p]);
+      }
+      Brow[k] = b;
+      cmac_r(dlt, b, -l.u[k]);
     }
   }
   // B_t[:,k] = sum_p (N_p x) c_kp dmono_kp(u)  (linearize.py:50-59);  Delta_t = f - A_t x - B_t u = -B_t u (:68-69)
@@ -205,18 +303,37 @@ struct FusedProv {
     Poly<NU, ORDER> po;
     po.eval(l.u);
     S nx[NP];
-    if constexpr (sizeof(S) == sizeof(double)) {
+#ifndef M4Q_FWD_BATCH
+#define M4Q_FWD_BATCH 1      // (measured A/B, config 3 real path: 51.2 -> 50.85 ms)
+#endif
+    if constexpr (M4Q_FWD_BATCH && sizeof(S) == sizeof(double) && NX <= 9) {
+      // as below with the (1 + NP) NX row elements read from LDS in one batch
+      S row[1 + NP][NX];
+#pragma unroll
+      for (int p = 0; p <= NP; ++p) {
+#pragma unroll
+        for (int k = 0; k < NX; ++k) row[p][k] = mld(mdl, ModelPitch<NX>::at(p, j, k));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+#pragma unroll
+        for (int k = 0; k < NX; ++k) cmac_r(row[0][k], row[1 + p][k], po.pu[p]);
+        nx[p] = dot_lane_index<false, false, NX>(l.xg, row[1 + p]);
+      }
+      av = dot_lane_index<false, false, NX>(v, row[0]);
+    } else if constexpr (sizeof(S) == sizeof(double)) {
       // real path: whole rows in registers, one long dot per accumulator (8 FMAs per statement)
       //   av = sum_k lane_k(v) A_t[j][k],   nx[p] = sum_k lane_k(xg) N_p[j][k]
       S arow[NX];
 #pragma unroll
-      for (int k = 0; k < NX; ++k) arow[k] = mdl[ModelPitch<NX>::at(0, j, k)];
+      for (int k = 0; k < NX; ++k) arow[k] = mld(mdl, ModelPitch<NX>::at(0, j, k));
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         S nrow[NX];
 #pragma unroll
         for (int k = 0; k < NX; ++k) {
-          nrow[k] = mdl[ModelPitch<NX>::at(1 + p, j, k)];
+          nrow[k] = mld(mdl, ModelPitch<NX>::at(1 + p, j, k));
           cmac_r(arow[k], nrow[k], po.pu[p]);
         }
         nx[p] = dot_lane_index<false, false, NX>(l.xg, nrow);
@@ -230,10 +347,10 @@ struct FusedProv {
       static_for<0, NX>([&](auto kk) {
         constexpr int k = decltype(kk)::value;
         S own[NP + 1];
-        own[NP] = mdl[ModelPitch<NX>::at(0, j, k)];
+        own[NP] = mld(mdl, ModelPitch<NX>::at(0, j, k));
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-          own[p] = mdl[ModelPitch<NX>::at(1 + p, j, k)];
+          own[p] = mld(mdl, ModelPitch<NX>::at(1 + p, j, k));
           cmac_r(own[NP], own[p], po.pu[p]);
         }
         emit_terms<IdxSameLaneVec<k>, false, false, false, 0, NP + 1>(accs, srcs, own);
@@ -261,6 +378,8 @@ struct FusedProv {
 
 template <int NX, int NU>
 struct ExplicitProv {
+  static constexpr int ORDER_ = 1;
+  const cplx* mdl = nullptr;
   GView A_ls;   // [T][NX][NX]   positioned at this instance
   GView B_ls;   // [T][NX][NU]
   GView D_ls;   // [T][NX]
@@ -273,6 +392,10 @@ struct ExplicitProv {
   __device__ __forceinline__ void col(const Lin& l, cplx (&Ac)[NX]) const {
 #pragma unroll
     for (int i = 0; i < NX; ++i) Ac[i] = A_ls.ld<cplx>((l.t * NX + i) * NX + j);
+  }
+  __device__ __forceinline__ void col_rows(const Lin& l, cplx v, cplx (&Ac)[NX], cplx& av, cplx (&Brow)[NU], cplx& dlt) const {
+    col(l, Ac);
+    rows(l, v, av, Brow, dlt);
   }
   __device__ __forceinline__ void rows(const Lin& l, cplx v, cplx& av, cplx (&Brow)[NU], cplx& dlt) const {
     cplx arow[NX];
@@ -398,6 +521,18 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
     for (int k = 0; k < NU; ++k) o.ub[k] = win.ubm.ld<double>(t * NU + k);
     return o;
   };
+#ifndef M4Q_HOIST_MODEL
+#define M4Q_HOIST_MODEL 2
+#endif
+  // n = 16 real path: one wavefront per SIMD owns all 512 registers, and alone on its SIMD it cannot hide the LDS
+  // read-to-use latency of the model at every horizon index: the ROW form of the model is read once per sweep and kept in
+  // registers (mode 2; measured A/B on config 4: 92.9 -> 85.8 ms; both forms, mode 1, spill: 87.5 ms; a per-index batch
+  // as for n <= 9 changes nothing: 92.9 ms)
+  constexpr bool HOIST = M4Q_HOIST_MODEL && std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && sizeof(S) == sizeof(double) &&
+                         NX == 16;
+  ModelRegs<S, NX, NU, Prov::ORDER_> mregs;
+  if constexpr (HOIST && M4Q_HOIST_MODEL == 2) mregs.load_rows(prov.mdl, j);
+  else if constexpr (HOIST) mregs.load(prov.mdl, j);
   auto step = [&](int t, const Ops& cur, Ops& nxt, const S (&Pc)[NX], const S pv, S (&Pn)[NX], S& pv_out) __attribute__((always_inline)) {
     M4Q_NO_HOIST();
     nxt = load(t > 0 ? t - 1 : 0);
@@ -406,11 +541,27 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
     const double (&ub)[NU] = cur.ub;
 
     S Ac[NX];
-    prov.col(lin, Ac);
-    M4Q_PHASE();
     const S xb1 = xb_next;
     S ax, Brow[NU], dlt;
-    prov.rows(lin, xb, ax, Brow, dlt);
+#ifndef M4Q_LDS_BATCH
+#define M4Q_LDS_BATCH 1
+#endif
+    // (measured, config 3 real path, A/B on one box: 51.98 -> 50.38 ms; n = 16 would need 256 registers for the batch)
+#ifndef M4Q_BATCH16
+#define M4Q_BATCH16 0
+#endif
+    if constexpr (HOIST && M4Q_HOIST_MODEL == 2) {
+      prov.col(lin, Ac);
+      prov.rows(mregs, lin, xb, ax, Brow, dlt);
+    } else if constexpr (HOIST) {
+      prov.col_rows(mregs, lin, xb, Ac, ax, Brow, dlt);
+    } else if constexpr (M4Q_LDS_BATCH && sizeof(S) == sizeof(double) && (NX <= 9 || M4Q_BATCH16)) {
+      prov.col_rows(lin, xb, Ac, ax, Brow, dlt);
+    } else {
+      prov.col(lin, Ac);
+      M4Q_PHASE();
+      prov.rows(lin, xb, ax, Brow, dlt);
+    }
     M4Q_PHASE();
 
     // affine column of the augmented dynamics
@@ -534,6 +685,16 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
     for (int k = 0; k < NU; ++k) cmac(s, Brow[k], kk[k]);
     M4Q_PHASE();
 
+#ifndef M4Q_Q_EARLY
+#define M4Q_Q_EARLY 0
+#endif
+    const S* Qt = cost.q(t, T);
+    S Qcol[NX];
+    if constexpr (M4Q_Q_EARLY) {
+      // column j of Q_t is fetched from LDS before the 2 n^3 products instead of between them
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Qcol[i] = Qt[i * NX + j];
+    }
     S PSc[NX];
     matmul_cols<NX>(PSc, Pc, Ac);                              // P Sx
     const S ws = dot_lane_index<false, true, NX>(s, Pc, pv);  // (P s + p)_j
@@ -551,9 +712,8 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
         cmac(Rk[k], rkl, kk[l]);
       }
     }
-    const S* Qt = cost.q(t, T);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) Pn[i] = Qt[i * NX + j];
+    for (int i = 0; i < NX; ++i) Pn[i] = M4Q_Q_EARLY ? Qcol[i] : Qt[i * NX + j];
     matmul_cols_hn_acc<NX>(Pn, Ac, PSc);                       // + Sx^H P Sx
 #pragma unroll
     for (int k = 0; k < NU; ++k) mac_lane_index<true, false, NX>(Pn, Kx[k], RK[k]);   // + Kx^H R Kx
@@ -568,7 +728,19 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
   S Pd[NX];
   S pd = zero_of<S>();
   Ops opsA = load(T - 1), opsB;
-  if constexpr (sizeof(S) == sizeof(double)) {
+  // The two-index form is off for S = cplx.  It brings nothing there (the complex path is bound by FMA issue, not by the
+  // copies) and the d = 4 instantiation is BROKEN: built with -DM4Q_TWO_INDEX_COMPLEX=1 (tools/build_variant.sh), the first
+  // closed-loop launch of shape (16, 3, 1) aborted inside hipStreamSynchronize on one run and hung until my timeout killed it
+  // on the next (profiles/r02_two_index_complex_d4_fault.log) - corrupted control flow or addresses, not arithmetic.  Checked
+  // and ruled out: kernel resources (256 + 256 registers, 292 B/lane scratch, 154 SGPR spills: all next to the working
+  // one-index build's 244 B and 150), the > 64 KB dynamic-LDS attribute (same 77 KB in both), code size / long branches (137 KB,
+  // 5 s_getpc/s_setpc expansions, scratch SGPRs dead at every target; shipping kernels of 225 KB with the same expansions run),
+  // the trip logic and GView offsets (the same source runs as S = double on every shape).  What differs is register-file
+  // traffic at 100 % occupancy of the file: 651 v_accvgpr_read against 276.  Cause not isolated; not run again.
+#ifndef M4Q_TWO_INDEX_COMPLEX
+#define M4Q_TWO_INDEX_COMPLEX 0
+#endif
+  if constexpr (sizeof(S) == sizeof(double) || M4Q_TWO_INDEX_COMPLEX) {
     int t = T - 1;
     for (; t >= 1; t -= 2) {
       step(t, opsA, opsB, Pc, pv, Pd, pd);
@@ -639,11 +811,14 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
   };
   // one horizon index: `cur` holds its operands, those of the next index are fetched into `nxt` meanwhile.  The loop
   // below runs two indices per trip with the two operand sets swapping roles, so that no set is ever copied.
-  auto step = [&](int t, const Ops& cur, Ops& nxt) __attribute__((always_inline)) {
-    M4Q_NO_HOIST();
-    nxt = load(t + 1 < T ? t + 1 : t);
+  constexpr bool HOIST = M4Q_HOIST_MODEL && std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && sizeof(S) == sizeof(double) &&
+                         NX == 16;
+  ModelRegs<S, NX, NU, Prov::ORDER_> mregs;
+  if constexpr (HOIST) mregs.load_rows(prov.mdl, j);
+  auto step_body = [&](int t, const Ops& cur) __attribute__((always_inline)) {
     S ax, Brow[NU], dlt;
-    prov.rows(cur.lin, x, ax, Brow, dlt);
+    if constexpr (HOIST) prov.rows(mregs, cur.lin, x, ax, Brow, dlt);
+    else prov.rows(cur.lin, x, ax, Brow, dlt);
     M4Q_PHASE();
     const S dx = csub(x, cur.xb);
     double u[NU];
@@ -699,13 +874,40 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
     }
     M4Q_PHASE();
   };
-  Ops opsA = load(0), opsB;
-  int t = 0;
-  for (; t + 1 < T; t += 2) {
-    step(t, opsA, opsB);
-    step(t + 1, opsB, opsA);
+  auto step = [&](int t, const Ops& cur, Ops& nxt) __attribute__((always_inline)) {
+    M4Q_NO_HOIST();
+    nxt = load(t + 1 < T ? t + 1 : t);
+    step_body(t, cur);
+  };
+#ifndef M4Q_FWD_PF2
+#define M4Q_FWD_PF2 0
+#endif
+  if constexpr (M4Q_FWD_PF2 && !WANT_COST) {
+    // operands fetched TWO horizon indices ahead (three sets rotating): a step of the rollout is a short dependent chain
+    // (x_t -> u_t -> x_{t+1}), shorter than a workspace read that misses the L2
+    auto step2 = [&](int t, const Ops& cur, Ops& nxt2) __attribute__((always_inline)) {
+      M4Q_NO_HOIST();
+      nxt2 = load(t + 2 < T ? t + 2 : T - 1);
+      step_body(t, cur);
+    };
+    Ops o0 = load(0), o1 = load(T > 1 ? 1 : 0), o2;
+    int t = 0;
+    for (; t + 2 < T; t += 3) {
+      step2(t, o0, o2);
+      step2(t + 1, o1, o0);
+      step2(t + 2, o2, o1);
+    }
+    if (t < T) { step2(t, o0, o2); ++t; }
+    if (t < T) step2(t, o1, o0);
+  } else {
+    Ops opsA = load(0), opsB;
+    int t = 0;
+    for (; t + 1 < T; t += 2) {
+      step(t, opsA, opsB);
+      step(t + 1, opsB, opsA);
+    }
+    if (t < T) step(t, opsA, opsB);
   }
-  if (t < T) step(t, opsA, opsB);
   if constexpr (WANT_COST) {
     if (!ref) {
       const S e = csub(x, win.xbm.ld<S>(T * NX + j));

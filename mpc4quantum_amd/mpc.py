@@ -230,13 +230,10 @@ class _HeldControl:
         return self.y[..., idx]
 
 
-def mpc_batch(x0, models, dim_u, order, X_targ, U_targ, clock, plant_op0, plant_ops, Q, R, Qf, sat, du=None,
-              max_iter=100, warm_start=True, qp_flags=None, plant_kind=_lib.PLANT_HAMILTONIAN, device=-1, session=None,
-              force_complex=False, exact_qp=False):
-    """B independent closed loops in one launch.
-    x0 [B, n]; models [B|1, n, n(1+P)]; X_targ (n, cols) / U_targ (m, cols) shared (or [B, ...] each);
-    plant_op0 [B|1, k, k], plant_ops [B|1, m, k, k].  Returns a dict: xs [B, n, n_steps+1], us [B, m, n_steps]
-    (entries beyond steps_done are not meaningful), exit_codes, steps_done, qp_solves [B, n_steps]."""
+def open_session(x0, models, dim_u, order, X_targ, U_targ, clock, plant_op0, plant_ops, Q, R, Qf, sat, du=None,
+                 max_iter=100, warm_start=True, qp_flags=None, plant_kind=_lib.PLANT_HAMILTONIAN, device=-1,
+                 force_complex=False, exact_qp=False):
+    """An EnsembleSession loaded with mpc_batch's arguments (everything resident in HBM, nothing run yet)."""
     x0 = np.ascontiguousarray(x0, dtype=np.complex128)
     Bn, n = x0.shape
     models = np.asarray(models, dtype=np.complex128)
@@ -256,21 +253,34 @@ def mpc_batch(x0, models, dim_u, order, X_targ, U_targ, clock, plant_op0, plant_
     per_targ = X_targ.ndim == 3
     T, ns = clock.horizon, clock.n_steps
     cols = min(X_targ.shape[-1], ns + T + 1)
-    own = session is None
-    sess = session or EnsembleSession(Bn, n, dim_u, order, T, ns, clock.dt, sat, du, max_iter, warm_start, qp_flags,
-                                      plant_kind, models.shape[0] > 1, per_plant, per_targ, cols, device=device,
-                                      force_complex=force_complex, measure_freq=getattr(clock, "measure_freq", 1),
-                                      exact_qp=exact_qp)
+    sess = EnsembleSession(Bn, n, dim_u, order, T, ns, clock.dt, sat, du, max_iter, warm_start, qp_flags, plant_kind,
+                           models.shape[0] > 1, per_plant, per_targ, cols, device=device, force_complex=force_complex,
+                           measure_freq=getattr(clock, "measure_freq", 1), exact_qp=exact_qp)
     try:
         sess.load_problem(models, x0, X_targ, U_targ, Q, R, Qf, op0, ops)
-        sess.run(0, ns)
+    except Exception:
+        sess.close()
+        raise
+    return sess
+
+
+def mpc_batch(x0, models, dim_u, order, X_targ, U_targ, clock, plant_op0, plant_ops, Q, R, Qf, sat, du=None,
+              max_iter=100, warm_start=True, qp_flags=None, plant_kind=_lib.PLANT_HAMILTONIAN, device=-1,
+              force_complex=False, exact_qp=False):
+    """B independent closed loops in one launch.
+    x0 [B, n]; models [B|1, n, n(1+P)]; X_targ (n, cols) / U_targ (m, cols) shared (or [B, ...] each);
+    plant_op0 [B|1, k, k], plant_ops [B|1, m, k, k].  Returns a dict: xs [B, n, n_steps+1], us [B, m, n_steps]
+    (entries beyond steps_done are not meaningful), exit_codes, steps_done, qp_solves [B, n_steps]."""
+    sess = open_session(x0, models, dim_u, order, X_targ, U_targ, clock, plant_op0, plant_ops, Q, R, Qf, sat, du, max_iter,
+                        warm_start, qp_flags, plant_kind, device, force_complex, exact_qp)
+    try:
+        sess.run(0, clock.n_steps)
         res = sess.results()
         res["path"] = sess.path()
         res["kernel_ms"] = sess.kernel_ms()[0]
         res["qp_stats"] = sess.qp_stats()
     finally:
-        if own:
-            sess.close()
+        sess.close()
     res["xs"] = np.swapaxes(res["xs"], 1, 2)
     res["us"] = np.swapaxes(res["us"], 1, 2)
     return res

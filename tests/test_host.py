@@ -206,6 +206,31 @@ def test_shard_bounds_cover_everything():
 
 
 # ---------------------------------------------------------------- C ABI surface
+@pytest.mark.parametrize("final_only", [False, True])
+def test_result_layout_roundtrip_and_alignment(final_only):
+    """The byte layout of the multi-GPU gather buffer: regions 16-byte aligned and disjoint, pack/unpack inverse of each
+    other for a block shorter than the buffer."""
+    from mpc4quantum_amd.distributed import ResultLayout
+    rng = np.random.default_rng(3)
+    rows, k, n, m, ns = 7, 5, 9, 2, 6
+    lay = ResultLayout(rows, n, m, ns, final_only)
+    ends = 0
+    for f in ResultLayout.FIELDS:
+        assert lay.offset[f] % 16 == 0 and lay.offset[f] >= ends
+        ends = lay.offset[f] + lay.field_bytes(f)
+    assert lay.nbytes >= ends
+    res = {"xs": rng.standard_normal((k, ns + 1, n)) + 1j * rng.standard_normal((k, ns + 1, n)),
+           "us": rng.standard_normal((k, ns, m)), "exit_codes": rng.integers(0, 4, k).astype(np.int32),
+           "steps_done": rng.integers(0, ns + 1, k).astype(np.int32), "qp_solves": rng.integers(0, 100, (k, ns)).astype(np.int32)}
+    buf = np.zeros(lay.nbytes, dtype=np.uint8)
+    lay.pack(res, buf)
+    back = lay.unpack(buf, k)
+    assert np.array_equal(back["xs"], res["xs"][:, -1:] if final_only else res["xs"])
+    for f in ResultLayout.FIELDS[1:]:
+        assert np.array_equal(back[f], res[f]) and back[f].dtype == res[f].dtype
+    assert not lay.view(buf, "us")[k:].any()                    # padding rows stay zero
+
+
 def test_abi_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "m4q.h")).read()
     declared = set(re.findall(r"M4Q_API[^;(]*?\b(m4q_[a-z_0-9]+)\s*\(", header))
