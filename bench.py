@@ -59,6 +59,25 @@ def pmc_record(key, avg_launch_ms):
     return rec, None
 
 
+def usable_cores():
+    """Host cores this job may actually use: the affinity mask, cut to the cgroup CPU quota when there is one (the GPU boxes show
+    all 256 hardware threads in the mask but give a one-GPU job cpu.max = 16 cores; 256 workers on that share ran 30x slower each)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, (q + per // 2) // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -119,7 +138,7 @@ def cpu_baseline(config, p, cores, seconds_budget=20.0, members_per_core=64):
     wall = max(r["seconds"] for r in results)
     return {"value": units / wall, "unit": "MPC horizon-steps/s", "cores": len(results), "kind": "port",
             "per_core": units / sum(r["seconds"] for r in results), "cpu": cpu_model(),
-            "host_cores_available": len(os.sched_getaffinity(0)),
+            "host_threads_visible": len(os.sched_getaffinity(0)), "host_cores_usable": usable_cores(),
             "sample": "%d of %d ensemble members (%d processes x ~%.0f s, one core each), full closed loop (n_steps=%d, T=%d), "
                       "NumPy oracle" % (sum(r["members"] for r in results), p["x0"].shape[0], len(results), wall, p["n_steps"],
                                         p["horizon"])}
@@ -135,7 +154,8 @@ def main():
     ap.add_argument("--config", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="ensemble members per GPU (default: the config's own size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-cores", type=int, default=0, help="host cores for the CPU baseline (0 = all this process may use)")
+    ap.add_argument("--cpu-cores", type=int, default=0, help="host cores for the CPU baseline (0 = all this job may use: affinity "
+                                                             "mask cut to the cgroup CPU quota)")
     ap.add_argument("--backend", default="nccl", help="collective backend for N > 1: nccl (= RCCL over xGMI, the real thing) or "
                                                       "gloo (rehearsal on a box with fewer GPUs than ranks: results staged through the host)")
     ap.add_argument("--exact-qp", action="store_true", help="not the headline: every QP solved to the box-constrained optimum "
@@ -249,12 +269,16 @@ def main():
             # lane row accesses as for wide streaming reads (tools/ubench_fetch.hip, profiles/r02_fetch_calibration.txt)
             if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 traffic = (rec.get("fetch_factor", 2.0) * c["FETCH_SIZE"] + rec.get("write_factor", 1.0) * c["WRITE_SIZE"]) * 1024.0
-            if "SQ_INSTS_VALU_FMA_F64" in c:
-                slots = 1024 * (rec["traced_avg_launch_ms"] * 1e-3 * 2.4e9) / 4.0      # fp64 FMA wave-instruction slots of the chip
+            if "SQ_INSTS_VALU_FMA_F64" in c and "GRBM_GUI_ACTIVE" in c:
+                cycles = c["GRBM_GUI_ACTIVE"] / 8.0                       # shader cycles of the counted launch (sum over 8 XCDs)
+                slots = 1024 * cycles / 4.0                               # fp64 FMA wave-instruction slots: 1024 SIMDs, 4 cycles each
+                pmc_ms = sum(rec["pmc_pass_launch_ms"]) / len(rec["pmc_pass_launch_ms"])
                 issue = {"fma_f64_wave_insts": c["SQ_INSTS_VALU_FMA_F64"], "frac_of_fma_issue_slots": c["SQ_INSTS_VALU_FMA_F64"] / slots,
-                         "valu_busy": c.get("SQ_ACTIVE_INST_VALU", 0) / slots if "SQ_ACTIVE_INST_VALU" in c else None,
+                         "valu_busy": c["SQ_ACTIVE_INST_VALU"] / slots if "SQ_ACTIVE_INST_VALU" in c else None,
+                         "fma_share_of_valu_insts": c["SQ_INSTS_VALU_FMA_F64"] / c["SQ_INSTS_VALU"] if "SQ_INSTS_VALU" in c else None,
                          "wave_time_waiting": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"] if "SQ_WAVE_CYCLES" in c else None,
-                         "note": "all 64 lanes counted; at 2.4 GHz (the chip clocks lower under this load)"}
+                         "clock_ghz_under_load": cycles / (pmc_ms * 1e-3) / 1e9,
+                         "note": "from profiles/r02_pmc.json (separate --pmc passes on this binary); all 64 lanes counted"}
         out = {
             "metric": "MPC horizon-steps/sec across batch (3-level transmon, T=40)" if args.config == 3
                       else "MPC horizon-steps/sec across batch (config %d)" % args.config,
@@ -290,7 +314,7 @@ def main():
                                                 "within 3 %): L2-miss bytes per launch, mostly served by the Infinity Cache"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            cores = args.cpu_cores or len(os.sched_getaffinity(0))
+            cores = args.cpu_cores or usable_cores()
             out["cpu_baseline"] = cpu_baseline(args.config, p, cores)
         print(json.dumps(out))
     sess.close()

@@ -18,6 +18,7 @@ import csv
 import glob
 import json
 import os
+import shutil
 import subprocess
 import sys
 
@@ -68,6 +69,7 @@ def main():
     for i, group in enumerate(GROUPS):
         d = os.path.join(out, "pmc_tmp_%d" % i)
         log = os.path.join(out, "pmc_tmp_%d.log" % i)
+        shutil.rmtree(d, ignore_errors=True)               # (a reused directory would add an earlier configuration's dispatches)
         rc = run(["rocprofv3", "--pmc"] + group.split() + ["--output-format", "csv", "-d", d, "--"] + bench, log)
         line = bench_line(log) or line
         if rc != 0 or bench_line(log) is None:
@@ -81,6 +83,7 @@ def main():
     # traced run: kernel time without counters
     d = os.path.join(out, "trace_tmp")
     log = os.path.join(out, "trace_tmp.log")
+    shutil.rmtree(d, ignore_errors=True)
     rc = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--"] + bench[:3] + ["4", "--warmup", "1"] + bench[6:], log)
     traced = bench_line(log)
     b = traced or line
