@@ -179,6 +179,7 @@ struct m4q_session {
   DevBuf r_models, r_x0, r_xtarg, r_Q, r_Qf, r_R;
   bool herm_ok[M4Q_F_COUNT] = {};
   bool force_complex = false;
+  bool targ_const = false;      // every column of X_targ equals the first (per member, if per-member): xbar does not depend on t
   bool use_real() const {
     return !force_complex && ls_diag && herm_ok[M4Q_F_MODELS] && herm_ok[M4Q_F_X0] && herm_ok[M4Q_F_X_TARG] &&
            herm_ok[M4Q_F_Q] && herm_ok[M4Q_F_QF] && herm_ok[M4Q_F_R];
@@ -370,6 +371,14 @@ int m4q_session_upload(m4q_session* s, int32_t field, const void* host, size_t b
   if (field == M4Q_F_Q) { s->hQ.assign((const double*)host, (const double*)host + 2 * n * n); s->costs_dirty = true; }
   if (field == M4Q_F_QF) { s->hQf.assign((const double*)host, (const double*)host + 2 * n * n); s->costs_dirty = true; }
   if (field == M4Q_F_R) { s->hR.assign((const double*)host, (const double*)host + 2 * m * m); s->costs_dirty = true; }
+  if (field == M4Q_F_X_TARG) {
+    const size_t cols = s->prob.target_cols, items = bytes / (16 * n * cols);
+    bool same = true;
+    for (size_t it = 0; it < items && same; ++it)
+      for (size_t c = 1; c < cols && same; ++c)
+        same = std::memcmp(ch + (it * cols + c) * n, ch + it * cols * n, 16 * n) == 0;
+    s->targ_const = same;
+  }
   if (!s->force_complex) {
     if (field == M4Q_F_MODELS) rc = lift_upload(s, field, ch, bytes / (16 * n * n * (1 + P)), true, (int)(1 + P), s->r_models);
     if (field == M4Q_F_X0) rc = lift_upload(s, field, ch, bytes / (16 * n), false, 1, s->r_x0);
@@ -479,7 +488,8 @@ int m4q_session_run(m4q_session* s, int32_t step_begin, int32_t step_end) {
   const bool real_path = s->use_real();
   m4q::MpcArgs a{};
   a.B = s->B; a.T = p.horizon; a.n_steps = p.n_steps; a.max_iter = p.max_iter; a.warm_start = p.warm_start;
-  a.flags = p.qp_flags; a.step_begin = step_begin; a.step_end = step_end;
+  a.flags = p.qp_flags | (s->targ_const ? 256 : 0);      // 256 = QP_TARG_CONST (csrc/m4q_mpc.h), internal
+  a.step_begin = step_begin; a.step_end = step_end;
   a.measure_freq = p.measure_freq > 1 ? p.measure_freq : 1;
   a.dt = p.dt; a.sat = p.sat; a.du = p.du; a.ls_tol = p.ls_tol;
   a.models = real_path ? s->r_models.p : s->f[M4Q_F_MODELS].p; a.model_stride = p.model_per_instance ? (long)(n * n * (1 + P)) : 0;

@@ -280,7 +280,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
     const bool st = running && lane_ok;
     // M4Q_EXP: timing-only ablation builds (results are wrong): 1 fixed 3 SQP iterations, 2 no backward,
     // 4 no forward, 8 no line search, 16 no guess update, 32 no plant/shift
-    if constexpr (!EXACT && !(M4Q_EXP & 2)) riccati_backward<S, NX, NU>(prov, T, win, cost, a.flags, gains, j, st);
+    if constexpr (!EXACT && !(M4Q_EXP & 2)) {
+      // (xbar_t the same for every t: the sweep needs no row form of A_t - wave-uniform choice between two instantiations.
+      //  n = 16 only: config 4 85.5 -> 84.2 ms; at n = 9 the kernel with both instantiations is SLOWER, 50.65 -> 51.7 ms,
+      //  although it executes 27 vector instructions fewer per horizon index - profiles/r02_ab_experiments.txt)
+      if (M4Q_TARG_CONST && NX == 16 && (a.flags & QP_TARG_CONST)) riccati_backward<S, NX, NU, FusedProv<S, NX, NU, ORDER>, false, true>(prov, T, win, cost, a.flags, gains, j, st);
+      else riccati_backward<S, NX, NU>(prov, T, win, cost, a.flags, gains, j, st);
+    }
     wave_sync();
     double uapp[NU];
 #pragma unroll

@@ -8,6 +8,23 @@
 #pragma once
 #include "m4q_device.h"
 
+// Tuning switches (defaults = what the A/B runs of profiles/r02_ab_experiments.txt selected; tools/build_variant.sh overrides)
+#ifndef M4Q_LDS_BATCH
+#define M4Q_LDS_BATCH 1      // real path, n <= 9: model read from LDS in one batch per horizon index (51.98 -> 50.38 ms)
+#endif
+#ifndef M4Q_BATCH16
+#define M4Q_BATCH16 0        // the same at n = 16: no gain (92.9 ms either way)
+#endif
+#ifndef M4Q_HOIST_MODEL
+#define M4Q_HOIST_MODEL 2    // real path, n = 16: row form of the model in registers over a sweep (92.9 -> 85.8 ms); 1 = both forms
+#endif
+#ifndef M4Q_FWD_BATCH
+#define M4Q_FWD_BATCH 1      // rollout: the row form read in one batch (51.2 -> 50.85 ms)
+#endif
+#ifndef M4Q_TARG_CONST
+#define M4Q_TARG_CONST 1     // constant targets: A_t xbar from 1 + NP products formed once per sweep
+#endif
+
 namespace m4q {
 
 // QP semantics flags (mirrored in include/m4q.h)
@@ -15,6 +32,7 @@ enum : int {
   QP_REF_LQR = 1,   // reproduce lqr.py as written (no Delta, xbar_{t+1}==xbar_t, cost built on xbar, absolute cost)
   QP_DU_BAND = 2,   // clip the first control to u_prev +- du as well (optimize.py:29-30)
   QP_EXACT_BOX = 4, // solve the box-constrained QP to optimality (projected Newton) instead of clipping the Riccati rollout
+  QP_TARG_CONST = 256,   // internal (set by the host when every column of X_targ is the same): xbar_t does not depend on t
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -283,6 +301,62 @@ struct FusedProv {
     po.eval(l.u);
     rows_from(r, l, po, v, av, Brow, dlt);
   }
+  // Constant target (xbar_t = xbar for the whole window - every reference scenario but one): A_t xbar = A xbar + sum_p polyu_p
+  // (N_p xbar), so the 1 + NP products with xbar are formed ONCE per sweep (tt) and the row form of A_t - NX loads, NP NX FMAs to
+  // build it, an NX-term dot - is not needed in the sweep at all.
+  __device__ __forceinline__ void target_terms(S xbar, S (&tt)[1 + NP]) const {
+#pragma unroll
+    for (int p = 0; p <= NP; ++p) {
+      S row[NX];
+#pragma unroll
+      for (int k = 0; k < NX; ++k) row[k] = mld(mdl, ModelPitch<NX>::at(p, j, k));
+      tt[p] = dot_lane_index<false, false, NX>(xbar, row);
+    }
+  }
+  __device__ __forceinline__ S av_from_terms(const Poly<NU, ORDER>& po, const S (&tt)[1 + NP]) const {
+    S av = tt[0];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) cmac_r(av, tt[1 + p], po.pu[p]);
+    return av;
+  }
+  __device__ __forceinline__ void col_rows_tc(const Lin& l, const S (&tt)[1 + NP], S (&Ac)[NX], S& av, S (&Brow)[NU], S& dlt) const {
+    Poly<NU, ORDER> po;
+    po.eval(l.u);
+    S col[1 + NP][NX], row[NP][NX];
+#pragma unroll
+    for (int p = 0; p <= NP; ++p) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) col[p][i] = mld(mdl, ModelPitch<NX>::at(p, i, j));
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+#pragma unroll
+      for (int k = 0; k < NX; ++k) row[p][k] = mld(mdl, ModelPitch<NX>::at(1 + p, j, k));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      S a = col[0][i];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) cmac_r(a, col[1 + p][i], po.pu[p]);
+      Ac[i] = a;
+    }
+    S nx[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) nx[p] = dot_lane_index<false, false, NX>(l.xg, row[p]);
+    av = av_from_terms(po, tt);
+    finish_rows(l, po, nx, Brow, dlt);
+  }
+  __device__ __forceinline__ void rows_tc(const ModelRegs<S, NX, NU, ORDER>& r, const Lin& l, const S (&tt)[1 + NP], S& av, S (&Brow)[NU],
+                                          S& dlt) const {
+    Poly<NU, ORDER> po;
+    po.eval(l.u);
+    S nx[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) nx[p] = dot_lane_index<false, false, NX>(l.xg, r.row[1 + p]);
+    av = av_from_terms(po, tt);
+    finish_rows(l, po, nx, Brow, dlt);
+  }
   __device__ __forceinline__ void finish_rows(const Lin& l, const Poly<NU, ORDER>& po, const S (&nx)[NP], S (&Brow)[NU], S& dlt) const {
     dlt = zero_of<S>();
 #pragma unroll
@@ -303,9 +377,6 @@ struct FusedProv {
     Poly<NU, ORDER> po;
     po.eval(l.u);
     S nx[NP];
-#ifndef M4Q_FWD_BATCH
-#define M4Q_FWD_BATCH 1      // (measured A/B, config 3 real path: 51.2 -> 50.85 ms)
-#endif
     if constexpr (M4Q_FWD_BATCH && sizeof(S) == sizeof(double) && NX <= 9) {
       // as below with the (1 + NP) NX row elements read from LDS in one batch
       S row[1 + NP][NX];
@@ -488,7 +559,7 @@ struct PinCtx {
   }
 };
 
-template <class S, int NX, int NU, class Prov, bool PINNED = false>
+template <class S, int NX, int NU, class Prov, bool PINNED = false, bool TC = false>
 __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const Window& win, const CostRef<S>& cost, int flags,
                                                   const GView& gains, int j, bool store_ok, PinCtx<NU>* pin = nullptr) {
   const bool ref = (flags & QP_REF_LQR) != 0;
@@ -521,9 +592,6 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
     for (int k = 0; k < NU; ++k) o.ub[k] = win.ubm.ld<double>(t * NU + k);
     return o;
   };
-#ifndef M4Q_HOIST_MODEL
-#define M4Q_HOIST_MODEL 2
-#endif
   // n = 16 real path: one wavefront per SIMD owns all 512 registers, and alone on its SIMD it cannot hide the LDS
   // read-to-use latency of the model at every horizon index: the ROW form of the model is read once per sweep and kept in
   // registers (mode 2; measured A/B on config 4: 92.9 -> 85.8 ms; both forms, mode 1, spill: 87.5 ms; a per-index batch
@@ -533,6 +601,11 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
   ModelRegs<S, NX, NU, Prov::ORDER_> mregs;
   if constexpr (HOIST && M4Q_HOIST_MODEL == 2) mregs.load_rows(prov.mdl, j);
   else if constexpr (HOIST) mregs.load(prov.mdl, j);
+  // constant target: real fused path with batched (n <= 9) or hoisted (n = 16, mode 2) model reads
+  constexpr bool TCON = TC && std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && sizeof(S) == sizeof(double) &&
+                        ((M4Q_LDS_BATCH && NX <= 9) || (HOIST && M4Q_HOIST_MODEL == 2));
+  S tterm[PowTab<NU, Prov::ORDER_>::NP + 1];
+  if constexpr (TCON) prov.target_terms(xb_next, tterm);
   auto step = [&](int t, const Ops& cur, Ops& nxt, const S (&Pc)[NX], const S pv, S (&Pn)[NX], S& pv_out) __attribute__((always_inline)) {
     M4Q_NO_HOIST();
     nxt = load(t > 0 ? t - 1 : 0);
@@ -543,14 +616,13 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
     S Ac[NX];
     const S xb1 = xb_next;
     S ax, Brow[NU], dlt;
-#ifndef M4Q_LDS_BATCH
-#define M4Q_LDS_BATCH 1
-#endif
     // (measured, config 3 real path, A/B on one box: 51.98 -> 50.38 ms; n = 16 would need 256 registers for the batch)
-#ifndef M4Q_BATCH16
-#define M4Q_BATCH16 0
-#endif
-    if constexpr (HOIST && M4Q_HOIST_MODEL == 2) {
+    if constexpr (TCON && HOIST) {
+      prov.col(lin, Ac);
+      prov.rows_tc(mregs, lin, tterm, ax, Brow, dlt);
+    } else if constexpr (TCON) {
+      prov.col_rows_tc(lin, tterm, Ac, ax, Brow, dlt);
+    } else if constexpr (HOIST && M4Q_HOIST_MODEL == 2) {
       prov.col(lin, Ac);
       prov.rows(mregs, lin, xb, ax, Brow, dlt);
     } else if constexpr (HOIST) {
