@@ -2,6 +2,8 @@
 (a) outputs of the reference's own files (tests/golden/*.npz) and (b) the CPU oracle on the same
 seeded inputs.  fp64 tolerances: 1e-10 relative for one QP solve / one MPC step,
 1e-8 after a 20-step closed loop."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1153,3 +1155,40 @@ def test_exact_qp_unconverged_solves_surface_as_exit_code_2():
                                     sat=p["sat"], du=p["du"], progress_bar=False, exact_qp=True)
     k = int(res["steps_done"][b])
     assert code == 2 and xs.shape == (9, k + 1) and (us is None if k == 0 else us.shape == (2, k)) and len(clock.ts_sim) == k
+
+
+def test_mpc_batch_sharded_nccl_single_rank(tmp_path):
+    """The product's multi-GPU function on its RCCL branch (backend "nccl", one rank - all a one-GPU box allows): the session's
+    outputs bound into the torch-owned gather buffer, one dist.gather of device memory, unpack.  Must equal mpc_batch bit for bit,
+    whole state history and final-state-only.  Runs in a child process (the process group and torch's CUDA context stay out of
+    the test process)."""
+    import subprocess
+    import sys
+    script = tmp_path / "sharded_nccl.py"
+    script.write_text('''
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+import torch, torch.distributed as dist
+import mpc4quantum_amd as m4q
+from mpc4quantum_amd import configs
+from mpc4quantum_amd.distributed import mpc_batch_sharded
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+p = configs.build(3, batch=10, horizon=12, n_steps=6)
+def clock(): return m4q.StepClock(p["dt"], p["horizon"], p["n_steps"])
+args = lambda: (p["x0"], p["models"], p["dim_u"], p["order"], p["X_targ"], p["U_targ"], clock(), p["plant_op0"], p["plant_ops"],
+                p["Q"], p["R"], p["Qf"], p["sat"], p["du"])
+ref = m4q.mpc_batch(*args())
+for final_only in (False, True):
+    got = mpc_batch_sharded(*args(), final_state_only=final_only)
+    xs = ref["xs"][:, :, -1:] if final_only else ref["xs"]
+    assert np.array_equal(got["xs"], xs), ("xs", final_only)
+    for k in ("us", "exit_codes", "steps_done", "qp_solves"):
+        assert np.array_equal(got[k], ref[k]), (k, final_only)
+dist.destroy_process_group()
+print("sharded nccl ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "sharded nccl ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
