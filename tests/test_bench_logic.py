@@ -1,0 +1,55 @@
+"""Host-side logic of bench.py that needs no GPU: the roofline inputs, the staleness rule for counter records, the CPU share."""
+import importlib.util
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("m4q_bench", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_executed_flops_and_compulsory_bytes():
+    b = _bench()
+    # 27 kflop per horizon-step for the complex recursion at d=3; the real path executes a quarter
+    assert b.executed_flop_per_hstep(9, "complex") == 27e3 and b.executed_flop_per_hstep(9, "real") == 6750.0
+    assert b.executed_flop_per_hstep(16, "real") == 126e3 / 4
+    # config 3, real path: model 8*9*27, x0 (16+8)*9, xs 16*9*21, us 8*2*20, guess 16*9*41 + 8*2*40, codes and counts 8 + 80
+    per = 8 * 9 * 27 + 24 * 9 + 16 * 9 * 21 + 8 * 2 * 20 + 16 * 9 * 41 + 8 * 2 * 40 + 8 + 80
+    assert b.compulsory_bytes(65536, 9, 2, 2, 40, 20, "real") == 65536 * per
+    assert b.compulsory_bytes(1, 9, 2, 2, 40, 20, "complex") - b.compulsory_bytes(1, 9, 2, 2, 40, 20, "real") == 8 * 9 * 27 + 8 * 9
+
+
+def test_counter_records_are_refused_when_stale(tmp_path, monkeypatch):
+    b = _bench()
+    rec = {"config3_B65536_real_clip": {"traced_avg_launch_ms": 50.0, "counters": {"FETCH_SIZE": 1.0}}}
+    path = tmp_path / "pmc.json"
+    path.write_text(json.dumps(rec))
+    monkeypatch.setattr(b, "PMC_JSON", str(path))
+    got, why = b.pmc_record("config3_B65536_real_clip", 50.9)          # within 3 %
+    assert got is not None and why is None
+    got, why = b.pmc_record("config3_B65536_real_clip", 52.0)          # 4 % off: the record describes another binary
+    assert got is None and "stale" in why
+    got, why = b.pmc_record("config4_B65536_real_clip", 85.0)
+    assert got is None and "no counter record" in why
+
+
+def test_committed_counter_records_cover_every_baseline_config():
+    recs = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
+    for key in ("config2_B8192_real_clip", "config3_B65536_real_clip", "config3_B65536_complex_clip", "config3_B65536_real_exact",
+                "config4_B65536_real_clip", "config5_B131072_real_clip"):
+        r = recs[key]
+        assert r["traced_avg_launch_ms"] > 0 and r["counters"]["SQ_INSTS_VALU_FMA_F64"] > 0
+        assert r["counters"]["SQ_INSTS_VALU_MFMA_MOPS_F64"] == 0            # no MFMA instruction in any of the kernels
+        # the HIP-event time of bench.py and rocprofv3's kernel-trace average of the same run agree
+        assert abs(r["hip_event_launch_ms_same_run"] - r["traced_avg_launch_ms"]) <= 0.02 * r["traced_avg_launch_ms"]
+
+
+def test_usable_cores_is_positive_and_bounded():
+    b = _bench()
+    n = b.usable_cores()
+    assert 1 <= n <= len(os.sched_getaffinity(0))
