@@ -186,6 +186,12 @@ template <> struct BasisIO<double> {
 // A_t.  rows(): for the row this lane owns, (A_t v)_j for a distributed vector v, row j of B_t and
 // Delta_t[j].  Views are positioned on this lane's instance; lane-dependent parts are 32-bit offsets.
 // ---------------------------------------------------------------------------------------------
+// Do the batched model reads fit the register file at two wavefronts per SIMD?  Both forms of (1 + NP) n x n blocks are 2 (1 + NP) n
+// doubles per lane: 54 at (n, m, order) = (9, 2, 1); at order 2 (NP = 5) the 108 doubles spill inside the horizon loop
+// (tools/hot_loops.py: 39 scratch loads per trip), so those shapes keep the interleaved reads.
+template <int NX, int NU, int ORDER>
+constexpr bool batch_fits() { return NX <= 9 && (1 + PowTab<NU, ORDER>::NP) * NX <= 27; }
+
 // one model element from LDS.  (M4Q_EXP & 256: timing-only ablation, results wrong - an opaque register copy instead of
 // the LDS read: what the launch would take without any LDS traffic or latency for the model)
 #ifndef M4Q_EXP
@@ -377,7 +383,7 @@ struct FusedProv {
     Poly<NU, ORDER> po;
     po.eval(l.u);
     S nx[NP];
-    if constexpr (M4Q_FWD_BATCH && sizeof(S) == sizeof(double) && NX <= 9) {
+    if constexpr (M4Q_FWD_BATCH && sizeof(S) == sizeof(double) && batch_fits<NX, NU, ORDER>()) {
       // as below with the (1 + NP) NX row elements read from LDS in one batch
       S row[1 + NP][NX];
 #pragma unroll
@@ -449,8 +455,7 @@ struct FusedProv {
 
 template <int NX, int NU>
 struct ExplicitProv {
-  static constexpr int ORDER_ = 1;
-  const cplx* mdl = nullptr;
+  static constexpr int ORDER_ = 1;   // (the QP kernels do not depend on the library order)
   GView A_ls;   // [T][NX][NX]   positioned at this instance
   GView B_ls;   // [T][NX][NU]
   GView D_ls;   // [T][NX]
@@ -603,7 +608,7 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
   else if constexpr (HOIST) mregs.load(prov.mdl, j);
   // constant target: real fused path with batched (n <= 9) or hoisted (n = 16, mode 2) model reads
   constexpr bool TCON = TC && std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && sizeof(S) == sizeof(double) &&
-                        ((M4Q_LDS_BATCH && NX <= 9) || (HOIST && M4Q_HOIST_MODEL == 2));
+                        ((M4Q_LDS_BATCH && batch_fits<NX, NU, Prov::ORDER_>()) || (HOIST && M4Q_HOIST_MODEL == 2));
   S tterm[PowTab<NU, Prov::ORDER_>::NP + 1];
   if constexpr (TCON) prov.target_terms(xb_next, tterm);
   auto step = [&](int t, const Ops& cur, Ops& nxt, const S (&Pc)[NX], const S pv, S (&Pn)[NX], S& pv_out) __attribute__((always_inline)) {
@@ -627,7 +632,7 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
       prov.rows(mregs, lin, xb, ax, Brow, dlt);
     } else if constexpr (HOIST) {
       prov.col_rows(mregs, lin, xb, Ac, ax, Brow, dlt);
-    } else if constexpr (M4Q_LDS_BATCH && sizeof(S) == sizeof(double) && (NX <= 9 || M4Q_BATCH16)) {
+    } else if constexpr (M4Q_LDS_BATCH && sizeof(S) == sizeof(double) && (batch_fits<NX, NU, Prov::ORDER_>() || M4Q_BATCH16)) {
       prov.col_rows(lin, xb, Ac, ax, Brow, dlt);
     } else {
       prov.col(lin, Ac);
