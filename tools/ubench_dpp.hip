@@ -57,8 +57,8 @@ __global__ __launch_bounds__(64) void k(double* out, int iters) {
 }
 
 template <int MODE>
-void run(const char* name, int waves_per_simd) {
-  const int grid = 256 * 4 * waves_per_simd, iters = 2000;
+void run(const char* name, int waves_per_simd, int iters = 2000) {
+  const int grid = 256 * 4 * waves_per_simd;
   double* d;
   hipMalloc(&d, (size_t)grid * 64 * 8);
   hipEvent_t e0, e1;
@@ -78,7 +78,17 @@ void run(const char* name, int waves_per_simd) {
   hipFree(d);
 }
 
-int main() {
+int main(int argc, char** argv) {
+  if (argc > 1) {
+    // `ubench_dpp long`: launches of ~0.1-0.2 s - the rate the chip SUSTAINS once its clock has settled under an fp64-dense load
+    // (the 1 ms launches below finish before it does)
+    for (int rep = 0; rep < 3; ++rep) {
+      run<0>("SUSTAINED v_fma_f64 x8 independent", 2, 300000);
+      run<1>("SUSTAINED v_fmac_f64_dpp x8 independent", 2, 300000);
+      run<5>("SUSTAINED v_fmac_f64_dpp dist 2 + s_nop 1 per 4", 2, 300000);
+    }
+    return 0;
+  }
   for (int w : {1, 2, 4}) {
     run<0>("v_fma_f64 x8 independent", w);
     run<1>("v_fmac_f64_dpp x8 independent", w);
