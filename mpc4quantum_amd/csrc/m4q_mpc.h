@@ -12,11 +12,9 @@
 #ifndef M4Q_LDS_BATCH
 #define M4Q_LDS_BATCH 1      // real path, n <= 9: model read from LDS in one batch per horizon index (51.98 -> 50.38 ms)
 #endif
-#ifndef M4Q_BATCH16
-#define M4Q_BATCH16 0        // the same at n = 16: no gain (92.9 ms either way)
-#endif
 #ifndef M4Q_HOIST_MODEL
-#define M4Q_HOIST_MODEL 2    // real path, n = 16: row form of the model in registers over a sweep (92.9 -> 85.8 ms); 1 = both forms
+#define M4Q_HOIST_MODEL 1    // real path, n = 16: ROW form of the model in registers over a sweep (92.9 -> 85.8 ms; both forms: 87.5,
+                             // 209 spills; a per-index batch as for n <= 9: 92.9)
 #endif
 #ifndef M4Q_FWD_BATCH
 #define M4Q_FWD_BATCH 1      // rollout: the row form read in one batch (51.2 -> 50.85 ms)
@@ -599,16 +597,14 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
   };
   // n = 16 real path: one wavefront per SIMD owns all 512 registers, and alone on its SIMD it cannot hide the LDS
   // read-to-use latency of the model at every horizon index: the ROW form of the model is read once per sweep and kept in
-  // registers (mode 2; measured A/B on config 4: 92.9 -> 85.8 ms; both forms, mode 1, spill: 87.5 ms; a per-index batch
-  // as for n <= 9 changes nothing: 92.9 ms)
+  // registers (measured A/B on config 4: 92.9 -> 85.8 ms; profiles/r02_ab_experiments.txt)
   constexpr bool HOIST = M4Q_HOIST_MODEL && std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && sizeof(S) == sizeof(double) &&
                          NX == 16;
   ModelRegs<S, NX, NU, Prov::ORDER_> mregs;
-  if constexpr (HOIST && M4Q_HOIST_MODEL == 2) mregs.load_rows(prov.mdl, j);
-  else if constexpr (HOIST) mregs.load(prov.mdl, j);
+  if constexpr (HOIST) mregs.load_rows(prov.mdl, j);
   // constant target: real fused path with batched (n <= 9) or hoisted (n = 16, mode 2) model reads
   constexpr bool TCON = TC && std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && sizeof(S) == sizeof(double) &&
-                        ((M4Q_LDS_BATCH && batch_fits<NX, NU, Prov::ORDER_>()) || (HOIST && M4Q_HOIST_MODEL == 2));
+                        ((M4Q_LDS_BATCH && batch_fits<NX, NU, Prov::ORDER_>()) || HOIST);
   S tterm[PowTab<NU, Prov::ORDER_>::NP + 1];
   if constexpr (TCON) prov.target_terms(xb_next, tterm);
   auto step = [&](int t, const Ops& cur, Ops& nxt, const S (&Pc)[NX], const S pv, S (&Pn)[NX], S& pv_out) __attribute__((always_inline)) {
@@ -627,12 +623,10 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
       prov.rows_tc(mregs, lin, tterm, ax, Brow, dlt);
     } else if constexpr (TCON) {
       prov.col_rows_tc(lin, tterm, Ac, ax, Brow, dlt);
-    } else if constexpr (HOIST && M4Q_HOIST_MODEL == 2) {
+    } else if constexpr (HOIST) {
       prov.col(lin, Ac);
       prov.rows(mregs, lin, xb, ax, Brow, dlt);
-    } else if constexpr (HOIST) {
-      prov.col_rows(mregs, lin, xb, Ac, ax, Brow, dlt);
-    } else if constexpr (M4Q_LDS_BATCH && sizeof(S) == sizeof(double) && (batch_fits<NX, NU, Prov::ORDER_>() || M4Q_BATCH16)) {
+    } else if constexpr (M4Q_LDS_BATCH && sizeof(S) == sizeof(double) && batch_fits<NX, NU, Prov::ORDER_>()) {
       prov.col_rows(lin, xb, Ac, ax, Brow, dlt);
     } else {
       prov.col(lin, Ac);
@@ -762,16 +756,6 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
     for (int k = 0; k < NU; ++k) cmac(s, Brow[k], kk[k]);
     M4Q_PHASE();
 
-#ifndef M4Q_Q_EARLY
-#define M4Q_Q_EARLY 0
-#endif
-    const S* Qt = cost.q(t, T);
-    S Qcol[NX];
-    if constexpr (M4Q_Q_EARLY) {
-      // column j of Q_t is fetched from LDS before the 2 n^3 products instead of between them
-#pragma unroll
-      for (int i = 0; i < NX; ++i) Qcol[i] = Qt[i * NX + j];
-    }
     S PSc[NX];
     matmul_cols<NX>(PSc, Pc, Ac);                              // P Sx
     const S ws = dot_lane_index<false, true, NX>(s, Pc, pv);  // (P s + p)_j
@@ -789,8 +773,9 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
         cmac(Rk[k], rkl, kk[l]);
       }
     }
+    const S* Qt = cost.q(t, T);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) Pn[i] = M4Q_Q_EARLY ? Qcol[i] : Qt[i * NX + j];
+    for (int i = 0; i < NX; ++i) Pn[i] = Qt[i * NX + j];
     matmul_cols_hn_acc<NX>(Pn, Ac, PSc);                       // + Sx^H P Sx
 #pragma unroll
     for (int k = 0; k < NU; ++k) mac_lane_index<true, false, NX>(Pn, Kx[k], RK[k]);   // + Kx^H R Kx
@@ -886,13 +871,16 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
     }
     return o;
   };
-  // one horizon index: `cur` holds its operands, those of the next index are fetched into `nxt` meanwhile.  The loop
-  // below runs two indices per trip with the two operand sets swapping roles, so that no set is ever copied.
   constexpr bool HOIST = M4Q_HOIST_MODEL && std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && sizeof(S) == sizeof(double) &&
                          NX == 16;
   ModelRegs<S, NX, NU, Prov::ORDER_> mregs;
   if constexpr (HOIST) mregs.load_rows(prov.mdl, j);
-  auto step_body = [&](int t, const Ops& cur) __attribute__((always_inline)) {
+  // one horizon index: `cur` holds its operands, those of the next index are fetched into `nxt` meanwhile.  The loop
+  // below runs two indices per trip with the two operand sets swapping roles, so that no set is ever copied.
+  // (Fetching two indices ahead with three rotating sets was measured: +1.6 %, profiles/r02_ab_experiments.txt.)
+  auto step = [&](int t, const Ops& cur, Ops& nxt) __attribute__((always_inline)) {
+    M4Q_NO_HOIST();
+    nxt = load(t + 1 < T ? t + 1 : t);
     S ax, Brow[NU], dlt;
     if constexpr (HOIST) prov.rows(mregs, cur.lin, x, ax, Brow, dlt);
     else prov.rows(cur.lin, x, ax, Brow, dlt);
@@ -951,40 +939,14 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
     }
     M4Q_PHASE();
   };
-  auto step = [&](int t, const Ops& cur, Ops& nxt) __attribute__((always_inline)) {
-    M4Q_NO_HOIST();
-    nxt = load(t + 1 < T ? t + 1 : t);
-    step_body(t, cur);
-  };
-#ifndef M4Q_FWD_PF2
-#define M4Q_FWD_PF2 0
-#endif
-  if constexpr (M4Q_FWD_PF2 && !WANT_COST) {
-    // operands fetched TWO horizon indices ahead (three sets rotating): a step of the rollout is a short dependent chain
-    // (x_t -> u_t -> x_{t+1}), shorter than a workspace read that misses the L2
-    auto step2 = [&](int t, const Ops& cur, Ops& nxt2) __attribute__((always_inline)) {
-      M4Q_NO_HOIST();
-      nxt2 = load(t + 2 < T ? t + 2 : T - 1);
-      step_body(t, cur);
-    };
-    Ops o0 = load(0), o1 = load(T > 1 ? 1 : 0), o2;
-    int t = 0;
-    for (; t + 2 < T; t += 3) {
-      step2(t, o0, o2);
-      step2(t + 1, o1, o0);
-      step2(t + 2, o2, o1);
-    }
-    if (t < T) { step2(t, o0, o2); ++t; }
-    if (t < T) step2(t, o1, o0);
-  } else {
-    Ops opsA = load(0), opsB;
-    int t = 0;
-    for (; t + 1 < T; t += 2) {
-      step(t, opsA, opsB);
-      step(t + 1, opsB, opsA);
-    }
-    if (t < T) step(t, opsA, opsB);
+
+  Ops opsA = load(0), opsB;
+  int t = 0;
+  for (; t + 1 < T; t += 2) {
+    step(t, opsA, opsB);
+    step(t + 1, opsB, opsA);
   }
+  if (t < T) step(t, opsA, opsB);
   if constexpr (WANT_COST) {
     if (!ref) {
       const S e = csub(x, win.xbm.ld<S>(T * NX + j));
