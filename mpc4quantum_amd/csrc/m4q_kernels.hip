@@ -337,15 +337,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
 #pragma unroll
         for (int k = 0; k < NU; ++k) uapp[k] = Us.ld<double>(k);
         if (use_ls) {
+          // (these copies are latency bound: unrolled so that several loads are in flight)
           if (!qp.cur_is_a) {
-            if (lane_ok)
+            if (lane_ok) {
+#pragma unroll 8
               for (int t = 0; t <= T; ++t) Xo.st<S>(t * NX + j, Xs.ld<S>(t * NX + j));
+            }
+#pragma unroll 4
             for (int e = jj; e < T * NU; e += 16) Uo.st<double>(e, Us.ld<double>(e));
           }
         } else {
           // warm step (alpha = 1, mpc.py:208-212): the solution becomes the next guess, shifted (mpc.py:271-272)
-          if (lane_ok)
+          if (lane_ok) {
+#pragma unroll 8
             for (int t = 0; t <= T; ++t) Xg.st<S>(t * NX + j, Xs.ld<S>((t < T ? t + 1 : T) * NX + j));
+          }
+#pragma unroll 4
           for (int e = jj; e < T * NU; e += 16) Ug.st<double>(e, Us.ld<double>(e + NU < T * NU ? e + NU : e));
         }
       }

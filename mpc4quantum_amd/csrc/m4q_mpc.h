@@ -586,6 +586,8 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
     typename Prov::Lin lin;
     S xb;
     double ub[NU];
+    double stv[NU], uk[NU];   // PINNED: working set and iterate's controls at this index
+    S xk;                     // PINNED + derive: iterate's state
   };
   auto load = [&](int t) __attribute__((always_inline)) {
     Ops o;
@@ -593,6 +595,15 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
     o.xb = win.xbm.ld<S>(t * NX + j);
 #pragma unroll
     for (int k = 0; k < NU; ++k) o.ub[k] = win.ubm.ld<double>(t * NU + k);
+    if constexpr (PINNED) {
+#pragma unroll
+      for (int k = 0; k < NU; ++k) o.stv[k] = pin->stat.template ld<double>(t * NU + k);
+      if (pin->any_derive) {
+#pragma unroll
+        for (int k = 0; k < NU; ++k) o.uk[k] = pin->Uk.template ld<double>(t * NU + k);
+        o.xk = pin->Xk.template ld<S>(t * NX + j);
+      }
+    }
     return o;
   };
   // n = 16 real path: one wavefront per SIMD owns all 512 registers, and alone on its SIMD it cannot hide the LDS
@@ -675,11 +686,11 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
       //   G_ff du_f = -(H_f dx + h_f + G_fp du_p)
       double stv[NU];
 #pragma unroll
-      for (int k = 0; k < NU; ++k) stv[k] = pin->stat.template ld<double>(t * NU + k);
+      for (int k = 0; k < NU; ++k) stv[k] = cur.stv[k];
       if (pin->any_derive) {
         double uk[NU];
 #pragma unroll
-        for (int k = 0; k < NU; ++k) uk[k] = pin->Uk.template ld<double>(t * NU + k);
+        for (int k = 0; k < NU; ++k) uk[k] = cur.uk[k];
 #pragma unroll
         for (int k = 0; k < NU; ++k) {
           double gk = rowsum<NX>(real_of(cmul(cconj(Brow[k]), lam)));
@@ -698,7 +709,7 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
             if (store_ok && j == 0) pin->stat.template st<double>(t * NU + k, sv);
           }
         }
-        const S e = csub(pin->Xk.template ld<S>(t * NX + j), xb);
+        const S e = csub(cur.xk, xb);
         lam = dot_lane_index<false, true, NX>(lam, Ac, qrow_times<NX>(cost.q(t, T), e, j));   // Q_t e_t + A_t^H lam
       }
 #pragma unroll
@@ -1000,35 +1011,57 @@ __device__ __forceinline__ double rollout_policy(const Prov& prov, int T, S x0, 
   info.outside = false;
   info.alpha = 1.0;
   double cx = 0.0, cu = 0.0;
-  for (int t = 0; t < T; ++t) {
+  // operands of horizon index t+1 are fetched while index t computes (two sets swapping roles, as in rollout_forward): the
+  // step is a short dependent chain and every operand comes from the workspace, i.e. from beyond the L2
+  struct Ops {
+    typename Prov::Lin lin;
+    S xb;
+    double ub[NU], uk[NU], st[NU];
+    S Kx[NU];
+    double kre[NU];
+  };
+  auto load = [&](int t) __attribute__((always_inline)) {
+    Ops o;
+    o.lin = prov.fetch(t);
+    o.xb = win.xbm.ld<S>(t * NX + j);
+    const unsigned gt = (unsigned)t * (NX + 1) * NU;
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+      o.ub[k] = win.ubm.ld<double>(t * NU + k);
+      o.uk[k] = Uk.ld<double>(t * NU + k);
+      o.st[k] = pin.stat.template ld<double>(t * NU + k);
+      o.Kx[k] = gains.ld<S>(gt + j * NU + k);
+      o.kre[k] = real_of(gains.ld<S>(gt + NX * NU + k));
+    }
+    return o;
+  };
+  auto step = [&](int t, const Ops& cur, Ops& nxt) __attribute__((always_inline)) {
     M4Q_NO_HOIST();
-    const typename Prov::Lin lin = prov.fetch(t);
+    nxt = load(t + 1 < T ? t + 1 : t);
     S ax, Brow[NU], dlt;
-    prov.rows(lin, x, ax, Brow, dlt);
-    const S dx = csub(x, win.xbm.ld<S>(t * NX + j));
+    prov.rows(cur.lin, x, ax, Brow, dlt);
+    const S dx = csub(x, cur.xb);
     cx += dot_re(dx, qrow_times<NX>(cost.q(t, T), dx, j));
     const S* Rt = cost.r(t);
-    const unsigned gt = (unsigned)t * (NX + 1) * NU;
     S xn = cadd(ax, dlt);
     double un[NU], eu[NU];
 #pragma unroll
     for (int k = 0; k < NU; ++k) {
-      double pv;
-      const bool fixd = pin.pinned(t, k, pv);
-      const double ub = win.ubm.ld<double>(t * NU + k);
-      const double uk = Uk.ld<double>(t * NU + k);
-      const double part = real_of(cmul(gains.ld<S>(gt + j * NU + k), dx));
-      const double v = rowsum<NX>(part) + real_of(gains.ld<S>(gt + NX * NU + k)) + ub;
-      un[k] = fixd ? pv : v;
       double lo, hi;
       pin.box.template at<NU>(t, k, pin.lo0, pin.hi0, lo, hi);
+      const bool fixd = cur.st[k] != 0.0;
+      const double pv = cur.st[k] > 0.0 ? hi : lo;                 // pinned value (PinCtx::pinned)
+      const double uk = cur.uk[k];
+      const double part = real_of(cmul(cur.Kx[k], dx));
+      const double v = rowsum<NX>(part) + cur.kre[k] + cur.ub[k];
+      un[k] = fixd ? pv : v;
       const bool above = un[k] > hi, below = un[k] < lo;
       if (above || below) {
         info.outside = true;
         info.alpha = fmin(info.alpha, ((above ? hi : lo) - uk) / (un[k] - uk));        // u^k is feasible: 0 <= a < 1
       }
       if (clip) un[k] = fmin(fmax(un[k], lo), hi);
-      eu[k] = un[k] - ub;
+      eu[k] = un[k] - cur.ub[k];
       info.dmax = fmax(info.dmax, fabs(un[k] - uk));
       cmac_r(xn, Brow[k], un[k]);
     }
@@ -1044,7 +1077,14 @@ __device__ __forceinline__ double rollout_policy(const Prov& prov, int T, S x0, 
         for (int k = 0; k < NU; ++k) Uc.st<double>(t * NU + k, un[k]);
       }
     }
+  };
+  Ops opsA = load(0), opsB;
+  int t = 0;
+  for (; t + 1 < T; t += 2) {
+    step(t, opsA, opsB);
+    step(t + 1, opsB, opsA);
   }
+  if (t < T) step(t, opsA, opsB);
   const S e = csub(x, win.xbm.ld<S>(T * NX + j));
   cx += dot_re(e, qrow_times<NX>(cost.q(T, T), e, j));
   return rowsum<NX>(cx) + cu;
@@ -1059,12 +1099,28 @@ __device__ __forceinline__ double rollout_open(const Prov& prov, int T, S x0, co
   S x = x0;
   if (store_ok) Xc.st<S>(j, x);
   double cx = 0.0, cu = 0.0;
-  for (int t = 0; t < T; ++t) {
+  struct Ops {                      // operands of index t+1 fetched while index t computes (as rollout_policy)
+    typename Prov::Lin lin;
+    S xb;
+    double ub[NU], uin[NU];
+  };
+  auto load = [&](int t) __attribute__((always_inline)) {
+    Ops o;
+    o.lin = prov.fetch(t);
+    o.xb = win.xbm.ld<S>(t * NX + j);
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+      o.ub[k] = win.ubm.ld<double>(t * NU + k);
+      o.uin[k] = U.ld<double>(t * NU + k);
+    }
+    return o;
+  };
+  auto step = [&](int t, const Ops& cur, Ops& nxt) __attribute__((always_inline)) {
     M4Q_NO_HOIST();
-    const typename Prov::Lin lin = prov.fetch(t);
+    nxt = load(t + 1 < T ? t + 1 : t);
     S ax, Brow[NU], dlt;
-    prov.rows(lin, x, ax, Brow, dlt);
-    const S e = csub(x, win.xbm.ld<S>(t * NX + j));
+    prov.rows(cur.lin, x, ax, Brow, dlt);
+    const S e = csub(x, cur.xb);
     cx += dot_re(e, qrow_times<NX>(cost.q(t, T), e, j));
     const S* Rt = cost.r(t);
     double u[NU], eu[NU];
@@ -1073,8 +1129,8 @@ __device__ __forceinline__ double rollout_open(const Prov& prov, int T, S x0, co
     for (int k = 0; k < NU; ++k) {
       double lo, hi;
       box.at<NU>(t, k, lo0, hi0, lo, hi);
-      u[k] = fmin(fmax(U.ld<double>(t * NU + k), lo), hi);
-      eu[k] = u[k] - win.ubm.ld<double>(t * NU + k);
+      u[k] = fmin(fmax(cur.uin[k], lo), hi);
+      eu[k] = u[k] - cur.ub[k];
       cmac_r(xn, Brow[k], u[k]);
     }
 #pragma unroll
@@ -1089,7 +1145,14 @@ __device__ __forceinline__ double rollout_open(const Prov& prov, int T, S x0, co
         for (int k = 0; k < NU; ++k) Uc.st<double>(t * NU + k, u[k]);
       }
     }
+  };
+  Ops opsA = load(0), opsB;
+  int t = 0;
+  for (; t + 1 < T; t += 2) {
+    step(t, opsA, opsB);
+    step(t + 1, opsB, opsA);
   }
+  if (t < T) step(t, opsA, opsB);
   const S e = csub(x, win.xbm.ld<S>(T * NX + j));
   cx += dot_re(e, qrow_times<NX>(cost.q(T, T), e, j));
   return rowsum<NX>(cx) + cu;
