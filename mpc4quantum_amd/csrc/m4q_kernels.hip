@@ -47,6 +47,10 @@ extern __shared__ __align__(16) unsigned char m4q_lds_raw[];
 template <class S>
 __device__ __forceinline__ void stage_model(S* dst, const S* src, int jj) {
   constexpr int W = NX * (1 + NP);
+#ifndef M4Q_STAGE_UNROLL
+#define M4Q_STAGE_UNROLL 1
+#endif
+#pragma unroll M4Q_STAGE_UNROLL
   for (int e = jj; e < NX * W; e += 16) {
     const int i = e / W;
     const int pk = e - i * W;
@@ -384,8 +388,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
     const bool upd = solved && !fail && use_ls;       // warm steps wrote the shifted guess in the rollout
     // X_guess += alpha (X_opt - X_guess) (mpc.py:228-229)
     // (these small per-element passes are latency bound: unrolled so that several loads are in flight)
+#ifndef M4Q_UPD_UNROLL
+#define M4Q_UPD_UNROLL 8
+#endif
     if (!(M4Q_EXP & 16) && upd && lane_ok) {
-#pragma unroll 8
+#pragma unroll M4Q_UPD_UNROLL
       for (int t = 0; t <= T; ++t) {
         const S xg = Xg.ld<S>(t * NX + j), xo = Xo.ld<S>(t * NX + j);
         Xg.st<S>(t * NX + j, cadd(xg, cscale(csub(xo, xg), alpha)));
