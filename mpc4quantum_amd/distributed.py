@@ -122,6 +122,10 @@ class ShardedResults:
             if res is not None:                                  # (a rank without members sends its zeroed buffer)
                 self.layout.pack(res, self.buf.numpy())
         self.dist.gather(self.buf, self.outs, dst=self.dst, group=self.group)
+        if self.on_device:
+            # RCCL runs on its own stream and the session on another that torch knows nothing about: without this the next
+            # sess.run() could overwrite the buffer while it is still being sent
+            torch.cuda.current_stream().synchronize()
         return self.outs
 
     def unpack(self, counts):
