@@ -200,8 +200,10 @@ def main():
     if multi:
         # the product's multi-GPU path (mpc4quantum_amd/distributed.py): the session's outputs are bound into ONE torch-owned
         # device buffer [final states | us | codes | steps done | solve counts] and one RCCL gather moves it
+        # Two such buffers alternate: the gather of run k travels while the kernel of run k+1 computes (every run's
+        # gather is inside the timed region; the last one is waited for at the closing fence).
         from mpc4quantum_amd.distributed import ShardedResults
-        shard = ShardedResults(sess, B, dst=0, final_state_only=True)
+        shard = [ShardedResults(sess, B, dst=0, final_state_only=True) for _ in range(2)]
     if per_model:
         sess.build_models(p["dt"], p["generators"], p["scales"])
         models = None
@@ -210,14 +212,24 @@ def main():
     sess.load_problem(models, p["x0"], p["X_targ"], p["U_targ"], p["Q"], p["R"], p["Qf"], p["plant_op0"], p["plant_ops"])
     path = sess.path()
 
+    runs = [0]
+
     def one_step():
-        sess.run(0, ns)
         if multi:
-            shard.gather()                                         # the one collective of the job
+            sh = shard[runs[0] % 2]
+            runs[0] += 1
+            sh.wait()                                              # its previous gather (two runs ago) has landed
+            sh.bind()
+            sess.run(0, ns)
+            sh.gather(wait=False)                                  # the one collective of the job
+        else:
+            sess.run(0, ns)
 
     def fence():
         sess.sync()
         if multi:
+            for sh in shard:
+                sh.wait()
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()

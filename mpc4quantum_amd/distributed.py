@@ -92,24 +92,44 @@ class ShardedResults:
         dev = "cuda" if self.on_device else "cpu"
         self.buf = torch.zeros(self.layout.nbytes, dtype=torch.uint8, device=dev)
         self.xs_hist = None
-        if self.on_device:
-            base = self.buf.data_ptr()
-            for f in ResultLayout.FIELDS:
-                if f == "xs" and final_state_only:
-                    # the kernel writes the history into its own torch buffer; its last column is copied on the device
-                    self.xs_hist = torch.empty(sess.B * (p.n_steps + 1) * p.dim_x * 2, dtype=torch.float64, device=dev)
-                    sess.bind_output(_lib.F_XS, self.xs_hist.data_ptr(), self.xs_hist.numel() * 8)
-                    continue
-                # the session's field covers sess.B members: a prefix of the region sized for `rows`
-                sess.bind_output(self._FIELD_ID[f], base + self.layout.offset[f], sess.field_bytes(self._FIELD_ID[f]))
+        self.final_state_only = final_state_only
+        self.pending = None
+        if self.on_device and final_state_only:
+            # the kernel writes the history into its own torch buffer; its last column is copied on the device
+            self.xs_hist = torch.empty(sess.B * (p.n_steps + 1) * p.dim_x * 2, dtype=torch.float64, device=dev)
+        self.bind()
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.outs = [torch.empty_like(self.buf) for _ in range(self.world)] if self.rank == dst else None
 
-    def gather(self):
+    def bind(self):
+        """Point the session's output fields at THIS buffer (two ShardedResults can alternate on one session, so that the
+        gather of one run overlaps the next run's kernel)."""
+        if not self.on_device:
+            return
+        sess = self.sess
+        base = self.buf.data_ptr()
+        for f in ResultLayout.FIELDS:
+            if f == "xs" and self.final_state_only:
+                sess.bind_output(_lib.F_XS, self.xs_hist.data_ptr(), self.xs_hist.numel() * 8)
+                continue
+            # the session's field covers sess.B members: a prefix of the region sized for `rows`
+            sess.bind_output(self._FIELD_ID[f], base + self.layout.offset[f], sess.field_bytes(self._FIELD_ID[f]))
+
+    def wait(self):
+        """Block until a gather started with wait=False has completed (no-op otherwise)."""
+        if self.pending is not None:
+            self.pending.wait()
+            self.pending = None
+            if self.on_device:
+                self.torch.cuda.current_stream().synchronize()
+
+    def gather(self, wait=True):
         """The one collective of the job.  Call after sess.run(); returns the per-rank buffers on dst (device tensors with
-        nccl), None elsewhere.  The kernel runs on the session's own stream: it is drained first."""
+        nccl), None elsewhere.  The kernel runs on the session's own stream: it is drained first.  wait=False: return as
+        soon as the collective is enqueued (call wait() before this buffer is bound and written again)."""
         torch = self.torch
+        self.wait()
         self.sess.sync()
         if self.on_device:
             if self.xs_hist is not None:
@@ -121,6 +141,9 @@ class ShardedResults:
             res = self.sess.results()
             if res is not None:                                  # (a rank without members sends its zeroed buffer)
                 self.layout.pack(res, self.buf.numpy())
+        if not wait:
+            self.pending = self.dist.gather(self.buf, self.outs, dst=self.dst, group=self.group, async_op=True)
+            return self.outs
         self.dist.gather(self.buf, self.outs, dst=self.dst, group=self.group)
         if self.on_device:
             # RCCL runs on its own stream and the session on another that torch knows nothing about: without this the next
