@@ -156,6 +156,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cores", type=int, default=0, help="host cores for the CPU baseline (0 = all this job may use: affinity "
                                                              "mask cut to the cgroup CPU quota)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="time budget of every CPU-baseline worker")
     ap.add_argument("--backend", default="nccl", help="collective backend for N > 1: nccl (= RCCL over xGMI, the real thing) or "
                                                       "gloo (rehearsal on a box with fewer GPUs than ranks: results staged through the host)")
     ap.add_argument("--exact-qp", action="store_true", help="not the headline: every QP solved to the box-constrained optimum "
@@ -327,7 +328,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             cores = args.cpu_cores or usable_cores()
-            out["cpu_baseline"] = cpu_baseline(args.config, p, cores)
+            out["cpu_baseline"] = cpu_baseline(args.config, p, cores, args.cpu_seconds)
         print(json.dumps(out))
     sess.close()
     if multi:

@@ -1192,3 +1192,31 @@ print("sharded nccl ok")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "sharded nccl ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_bench_line_schema():
+    """bench.py prints ONE JSON line with the driver's contract fields, the roofline of the dominant kernel and the CPU baseline."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "512", "--cpu-cores",
+                          "2", "--cpu-seconds", "2"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["unit"] == "MPC horizon-steps/s" and d["dtype"] == "f64" and d["data"] == "synthetic" and d["scaling"] == "weak"
+    assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["instances_ok"] == 512
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] == "valu_f64" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["traffic"] is None and "no counter record" in r["traffic_note"]          # 512 members: not a profiled configuration
+    assert abs(d["value"] - d["config"]["qp_solves_per_step"] * d["config"]["horizon"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 2 and c["value"] > 0 and c["unit"] == d["unit"] and "sample" in c
