@@ -1220,3 +1220,40 @@ def test_bench_line_schema():
     assert abs(d["value"] - d["config"]["qp_solves_per_step"] * d["config"]["horizon"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 2 and c["value"] > 0 and c["unit"] == d["unit"] and "sample" in c
+
+
+def test_config5_whole_ensemble_on_one_gpu():
+    """Maximum size: BASELINE config 5's WHOLE ensemble (2^20 members, T = 80, 20 MPC steps; 8.9e8 horizon-steps) resident on one
+    MI355X (25 GB of its 288 GB), models built on the device.  Every member must finish with exit code 0, respect the box and the
+    du band, spend one QP solve per warm step; identical members at the two ends of the ensemble must produce identical bits; a
+    strided sample of the states must be Hermitian with unit trace."""
+    B = 1 << 20
+    p = configs.build(5, batch=B, host_models=False)
+    twin = B - 5
+    p["scales"][twin] = p["scales"][3]
+    p["x0"][twin] = p["x0"][3]
+    n, m, T, ns, d = p["dim_x"], p["dim_u"], p["horizon"], p["n_steps"], p["d"]
+    sess = m4q.EnsembleSession(B, n, m, p["order"], T, ns, p["dt"], p["sat"], p["du"], model_per_instance=True, target_cols=ns + T + 1)
+    try:
+        sess.build_models(p["dt"], p["generators"], p["scales"])
+        sess.load_problem(None, p["x0"], p["X_targ"], p["U_targ"], p["Q"], p["R"], p["Qf"], p["plant_op0"], p["plant_ops"])
+        assert sess.path() == "real"
+        sess.run(0, ns)
+        ms, launches = sess.kernel_ms()
+        codes = sess.download(_lib.F_CODES, (B,))
+        done = sess.download(_lib.F_STEPS_DONE, (B,))
+        solves = sess.download(_lib.F_QP_SOLVES, (B, ns))
+        us = sess.download(_lib.F_US, (B, ns, m))
+        xs = sess.download(_lib.F_XS, (B, ns + 1, n))
+        hbm = sess.info()["hbm_bytes"]
+    finally:
+        sess.close()
+    assert launches == 1 and hbm > 20e9
+    assert not codes.any() and np.all(done == ns)
+    assert solves[:, 2:].min() == 1 and solves[:, 2:].max() == 1
+    assert np.abs(us).max() <= p["sat"] * (1 + 1e-15) and np.abs(np.diff(us, axis=1))[:, 1:].max() <= p["du"] * (1 + 1e-12)
+    assert np.array_equal(xs[3], xs[twin]) and np.array_equal(us[3], us[twin])
+    rho = xs[::257].reshape(-1, ns + 1, d, d)
+    assert np.abs(rho.trace(axis1=2, axis2=3) - 1).max() < 1e-10 and np.abs(rho - np.swapaxes(rho.conj(), 2, 3)).max() < 1e-10
+    units = int(solves.astype(np.int64).sum()) * T
+    print("config 5 whole ensemble on one GPU: %.1f ms, %.3g horizon-steps/s, %.1f GB resident" % (ms, units / (ms * 1e-3), hbm / 1e9))
