@@ -312,3 +312,30 @@ def test_mpc_loop_nan_raises_like_the_reference(golden):
         assert str(c["raised"]) == "LinAlgError" and int(c["exit_code"]) == -1
         with pytest.raises(np.linalg.LinAlgError):
             oracle_loop(c)
+
+
+@pytest.mark.parametrize("d,m", [(2, 1), (3, 2), (4, 3)])
+def test_plant_step_is_the_solution_of_the_ode_mesolve_integrates(d, m):
+    """The reference's plant is qutip.mesolve on H = H0 + sum_k u_k(t) H_k (experiment.py:202-212) with the control held over each
+    step (interp1d kind='previous', mpc.py:258): d rho/dt = -i [H, rho], rho(0) = x0.reshape(d, d), output flattened row-major.
+    qutip is absent; an independent integrator of that very ODE (SciPy DOP853, rtol 1e-12) must land on the oracle's exact
+    propagator - which is what the HIP plant is held to."""
+    from scipy.integrate import solve_ivp
+    rng = np.random.default_rng(60 + d)
+
+    def herm():
+        M = rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))
+        return M + M.conj().T
+    H0, Hk = herm(), [herm() for _ in range(m)]
+    M = rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))
+    rho0 = M @ M.conj().T
+    rho0 /= np.trace(rho0).real
+    u = rng.uniform(-1, 1, m)
+    dt = 0.37
+    H = H0 + sum(uk * h for uk, h in zip(u, Hk))
+
+    def rhs(t, y):
+        rho = y.reshape(d, d)
+        return (-1j * (H @ rho - rho @ H)).reshape(-1)
+    sol = solve_ivp(rhs, (0.0, dt), rho0.reshape(-1).astype(complex), method="DOP853", rtol=1e-12, atol=1e-14)
+    assert np.abs(orc.plant_step(rho0.reshape(-1), u, H0, Hk, dt) - sol.y[:, -1]).max() <= 1e-10
