@@ -42,6 +42,8 @@ extern "C" {
 #define M4Q_E_UNSUPPORTED (-1001) /* (dim_x, dim_u, order) has no compiled kernel */
 #define M4Q_E_BADARG (-1002)
 #define M4Q_E_NODEVICE (-1003)
+#define M4Q_E_TIMEOUT (-1004) /* the closed-loop launch abandoned itself: its watchdog (M4Q_KERNEL_TIMEOUT_S, default 300 s of device
+                                 time) expired before every member had finished; results of that launch are not valid */
 
 /* qp_flags */
 #define M4Q_QP_REF_LQR 1 /* reproduce mpc4quantum/lqr.py:14-79 as written (no Delta, no du band) */

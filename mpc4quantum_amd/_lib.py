@@ -17,7 +17,7 @@ QP_DU_BAND = 2
 QP_EXACT_BOX = 4
 OPT_FORCE_COMPLEX = 1
 PLANT_NONE, PLANT_HAMILTONIAN, PLANT_GENERATOR = 0, 1, 2
-E_UNSUPPORTED, E_BADARG, E_NODEVICE = -1001, -1002, -1003
+E_UNSUPPORTED, E_BADARG, E_NODEVICE, E_TIMEOUT = -1001, -1002, -1003, -1004
 
 (F_MODELS, F_X0, F_X_TARG, F_U_TARG, F_Q, F_R, F_QF, F_OP0, F_OPS, F_XS, F_US, F_CODES, F_STEPS_DONE,
  F_QP_SOLVES, F_X_GUESS, F_U_GUESS) = range(16)

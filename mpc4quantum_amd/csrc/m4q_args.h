@@ -27,9 +27,11 @@ struct MpcArgs {
   cplx* Xg; double* Ug;                     // per-instance SQP guess  [B][T+1][n] complex, [B][T][m] (resumable state)
   // per resident row (grid*4 of them): working guess followed by the QP solution (S [2][rows][T+1][n], [2][rows][T][m]), gains (S)
   void* ws_Xg; double* ws_Ug; void* ws_gains;
-  int* queue;                               // 64 B zeroed before every launch: [0] next work item to hand out;
+  int* queue;                               // 64 B zeroed before every launch: [0] next work item to hand out; [1] set by the watchdog;
                                             // as u64 [1..3]: exact-QP counters (solves, Newton iterations, arc trials)
   int* head_done;                           // [B] set when an instance's head item (steps < 2) has been published; zeroed likewise
+  unsigned long long deadline_ticks;        // watchdog: the launch abandons itself (queue[1] = 1) once s_memrealtime (100 MHz) has
+                                            // advanced this far since the wavefront started; every wavefront reaches this exit
 };
 
 struct LinArgs {

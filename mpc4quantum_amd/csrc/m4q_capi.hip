@@ -179,6 +179,7 @@ struct m4q_session {
   DevBuf r_models, r_x0, r_xtarg, r_Q, r_Qf, r_R;
   bool herm_ok[M4Q_F_COUNT] = {};
   bool force_complex = false;
+  bool launched = false;        // a closed-loop launch has been enqueued since the watchdog flag was last read
   bool targ_const = false;      // every column of X_targ equals the first (per member, if per-member): xbar does not depend on t
   bool use_real() const {
     return !force_complex && ls_diag && herm_ok[M4Q_F_MODELS] && herm_ok[M4Q_F_X0] && herm_ok[M4Q_F_X_TARG] &&
@@ -322,6 +323,18 @@ size_t m4q_session_field_bytes(const m4q_session* s, int32_t field) {
   return s->fbytes[field];
 }
 
+// After the stream has drained: did the last closed-loop launch leave through its watchdog?
+static int check_watchdog(m4q_session* s) {
+  if (!s->launched) return 0;
+  s->launched = false;
+  int flag = 0;
+  HIP_TRY(hipMemcpy(&flag, (const char*)s->queue.p + 4, 4, hipMemcpyDeviceToHost));
+  if (flag)
+    return fail(M4Q_E_TIMEOUT, "the closed-loop kernel abandoned the launch: its watchdog expired (M4Q_KERNEL_TIMEOUT_S, default 300 s "
+                               "of device time) before every ensemble member had finished; this launch's results are not valid");
+  return 0;
+}
+
 // lift one uploaded input to the Hermitian basis: keeps the real part on the device (doubles), remembers whether the
 // imaginary part was negligible.  vec_len = n for vectors; matrices are n x n blocks laid side by side (nblk per row set).
 static int lift_upload(m4q_session* s, int32_t field, const std::complex<double>* src, size_t count_items, bool matrix, int nblk,
@@ -413,7 +426,7 @@ int m4q_session_download(m4q_session* s, int32_t field, void* host, size_t bytes
   if (bytes == 0) return 0;
   HIP_TRY(hipMemcpyAsync(host, s->f[field].p, bytes, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
-  return 0;
+  return check_watchdog(s);
 }
 
 int m4q_session_put_state(m4q_session* s, int32_t step, const void* host) {
@@ -512,6 +525,14 @@ int m4q_session_run(m4q_session* s, int32_t step_begin, int32_t step_end) {
   a.ws_gains = s->wsG.p;
   a.queue = (int*)s->queue.p;
   a.head_done = (int*)s->head_done.p;
+  {
+    double seconds = 300.0;                                  // below the 7 minutes of silence after which a GPU box kills a job
+    if (const char* e = std::getenv("M4Q_KERNEL_TIMEOUT_S")) {
+      const double v = std::atof(e);
+      if (v > 0) seconds = v;
+    }
+    a.deadline_ticks = (unsigned long long)(seconds * 1e8);  // s_memrealtime counts at 100 MHz
+  }
   HIP_TRY(hipMemsetAsync(s->queue.p, 0, 64, s->stream));
   HIP_TRY(hipMemsetAsync(s->head_done.p, 0, (size_t)s->B * 4, s->stream));
   if (step_begin == 0) {
@@ -538,13 +559,14 @@ int m4q_session_run(m4q_session* s, int32_t step_begin, int32_t step_end) {
   if (rc) return fail(rc, "mpc kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));
   HIP_TRY(hipEventRecord(e1, s->stream));
   s->pending.emplace_back(e0, e1);
+  s->launched = true;
   return 0;
 }
 
 int m4q_session_sync(m4q_session* s) {
   if (!s) return fail(M4Q_E_BADARG, "m4q_session_sync: null session");
   HIP_TRY(hipStreamSynchronize(s->stream));
-  return 0;
+  return check_watchdog(s);
 }
 
 int m4q_session_set_codes(m4q_session* s, const int32_t* codes) {

@@ -176,7 +176,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
   GView xt = gview(x_targ, 0, 0), ut = gview(a.u_targ, 0, 0), op0 = gview(a.op0, 0, 0), ops = gview(a.ops, 0, 0);
   wave_sync();
 
+  // Watchdog.  The loop below ends when the queue is empty and every row has finished, and a tail item waits for a flag another
+  // workgroup sets: exits that depend on data.  A persistent kernel whose wavefronts never finish takes the GPU (and on this pool
+  // the host's other GPUs) down with it, so every wavefront also leaves once the constant 100 MHz clock has advanced
+  // a.deadline_ticks since it started; the host finds queue[1] set and fails the launch loudly (M4Q_E_TIMEOUT).
+  const unsigned long long wd_start = __builtin_amdgcn_s_memrealtime();
   while (true) {
+    if (__builtin_amdgcn_s_memrealtime() - wd_start > a.deadline_ticks) {
+      if (threadIdx.x == 0) __hip_atomic_store(a.queue + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
     // ---- rows without work draw the next item; tail items wait (without blocking) for their head ----
     if (__any(need_new || pending)) {
       int nb = 0;

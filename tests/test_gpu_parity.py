@@ -1257,3 +1257,24 @@ def test_config5_whole_ensemble_on_one_gpu():
     assert np.abs(rho.trace(axis1=2, axis2=3) - 1).max() < 1e-10 and np.abs(rho - np.swapaxes(rho.conj(), 2, 3)).max() < 1e-10
     units = int(solves.astype(np.int64).sum()) * T
     print("config 5 whole ensemble on one GPU: %.1f ms, %.3g horizon-steps/s, %.1f GB resident" % (ms, units / (ms * 1e-3), hbm / 1e9))
+
+
+def test_kernel_watchdog_turns_a_launch_that_does_not_end_into_an_error(monkeypatch):
+    """The persistent kernel's exits depend on data (queue empty, every row finished, a tail waiting for its head's flag).  Every
+    wavefront therefore also leaves when the device's constant clock has advanced M4Q_KERNEL_TIMEOUT_S (default 300 s) since it
+    started, and the host reports M4Q_E_TIMEOUT instead of results.  Forced here with a deadline of 0.1 microseconds."""
+    p = configs.build(3, batch=8, horizon=12, n_steps=6)
+    sess = _session(p, 8)
+    try:
+        sess.load_problem(p["models"], p["x0"], p["X_targ"], p["U_targ"], p["Q"], p["R"], p["Qf"], p["plant_op0"], p["plant_ops"])
+        monkeypatch.setenv("M4Q_KERNEL_TIMEOUT_S", "1e-7")
+        sess.run()
+        with pytest.raises(_lib.M4qError) as err:
+            sess.sync()
+        assert err.value.code == _lib.E_TIMEOUT and "watchdog" in str(err.value)
+        monkeypatch.delenv("M4Q_KERNEL_TIMEOUT_S")
+        sess.run()                                             # the session stays usable
+        res = sess.results()
+        assert np.all(res["exit_codes"] == 0) and np.all(res["steps_done"] == 6)
+    finally:
+        sess.close()

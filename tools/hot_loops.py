@@ -50,7 +50,7 @@ def main():
                 continue
             body = L[amap[t]:i + 1]
             dpp = sum("v_fmac_f64_dpp" in x for x in body)
-            if dpp <= 100 or len(body) > 2500:
+            if dpp <= int(sys.argv[3] if len(sys.argv) > 3 else 100) or len(body) > 2500:
                 continue
             cnt = lambda p: sum(re.match(r"\s+" + p, x) is not None for x in body)   # noqa: E731
             print("   loop of %4d instructions: %4d v_fmac_f64_dpp, %3d other fp64 FMA, scratch loads %d stores %d, LDS reads %d, "
