@@ -132,6 +132,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
   cost.Q = ldsQ; cost.Qf = ldsQ + NX * NX; cost.q_stride = 0; cost.R = ldsQ + 2 * NX * NX; cost.r_stride = 0;
   // workspace of this resident row: wave-uniform base per workgroup, lane part = row within the wave
   const unsigned sX = (unsigned)(T + 1) * NX, sU = (unsigned)T * NU, sG = (unsigned)T * (NX + 1) * NU;
+#ifndef M4Q_WD_LDS
+#define M4Q_WD_LDS 1
+#endif
 #ifndef M4Q_EXP
 #define M4Q_EXP 0
 #endif
@@ -180,9 +183,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
   // workgroup sets: exits that depend on data.  A persistent kernel whose wavefronts never finish takes the GPU (and on this pool
   // the host's other GPUs) down with it, so every wavefront also leaves once the constant 100 MHz clock has advanced
   // a.deadline_ticks since it started; the host finds queue[1] set and fails the launch loudly (M4Q_E_TIMEOUT).
+#if M4Q_WD_LDS == 1
+  // (the deadline lives in LDS, not in two more scalar registers of a kernel that already spills 150 of them)
+  volatile unsigned long long* wd_slot = reinterpret_cast<volatile unsigned long long*>(ldsW + WLS_DOUBLES);
+  if (threadIdx.x == 0) *wd_slot = __builtin_amdgcn_s_memrealtime() + a.deadline_ticks;
+  wave_sync();
+#elif M4Q_WD_LDS == 0
   const unsigned long long wd_start = __builtin_amdgcn_s_memrealtime();
+#endif
   while (true) {
+#if M4Q_WD_LDS == 1
+    if (__builtin_amdgcn_s_memrealtime() > *wd_slot) {
+#elif M4Q_WD_LDS == 2
+    if (false) {                                   // timing experiment only: no watchdog
+#else
     if (__builtin_amdgcn_s_memrealtime() - wd_start > a.deadline_ticks) {
+#endif
       if (threadIdx.x == 0) __hip_atomic_store(a.queue + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       break;
     }
