@@ -809,7 +809,13 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
   // one-index build's 244 B and 150), the > 64 KB dynamic-LDS attribute (same 77 KB in both), code size / long branches (137 KB,
   // 5 s_getpc/s_setpc expansions, scratch SGPRs dead at every target; shipping kernels of 225 KB with the same expansions run),
   // the trip logic and GView offsets (the same source runs as S = double on every shape).  What differs is register-file
-  // traffic at 100 % occupancy of the file: 651 v_accvgpr_read against 276.  Cause not isolated; not run again.
+  // traffic at 100 % occupancy of the file: 651 v_accvgpr_read against 276.  Also ruled out on the disassembly: the three VGPRs that
+  // hold spilled SGPRs (v253-v255) are touched by v_writelane / v_readlane only - never copied to an AGPR or to scratch under a
+  // partial EXEC mask.  Later the same round, with the sweep's operand prefetch, the rollouts and the watchdog rewritten, the SAME
+  // variant build ran a staged probe (tests/probes/two_index_probe.py: one member / one step up to the faulting case) and 143 GPU
+  // tests without a fault, at the one-index build's speed (117.3 against 117.0 ms, config 4 complex, 16,384 members):
+  // profiles/r02_two_index_complex_d4_fault.log.  The fault is therefore not explained - a property of one build, not reproduced by
+  // the next - and the form stays off because it brings nothing.
 #ifndef M4Q_TWO_INDEX_COMPLEX
 #define M4Q_TWO_INDEX_COMPLEX 0
 #endif
