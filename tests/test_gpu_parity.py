@@ -1194,6 +1194,58 @@ print("sharded nccl ok")
     assert out.returncode == 0 and "sharded nccl ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 
 
+def test_mpc_batch_sharded_two_ranks_on_one_gpu(tmp_path):
+    """Two ranks (backend "gloo", both on the box's one GPU): each runs ITS contiguous block of an 11-member ensemble (6 + 5: the
+    padded-row case) through the HIP kernels, one gather puts the ensemble together on rank 0.  Must equal one mpc_batch over all
+    11 members bit for bit.  (RCCL itself cannot put two ranks on one device; its one-rank case is the test above.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "sharded_two.py"
+    script.write_text('''
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+import torch.distributed as dist
+import mpc4quantum_amd as m4q
+from mpc4quantum_amd import configs
+from mpc4quantum_amd.distributed import mpc_batch_sharded, shard_bounds
+rank = int(os.environ["RANK"])
+dist.init_process_group("gloo", rank=rank, world_size=2)
+p = configs.build(3, batch=11, horizon=12, n_steps=6)
+def clock(): return m4q.StepClock(p["dt"], p["horizon"], p["n_steps"])
+args = lambda: (p["x0"], p["models"], p["dim_u"], p["order"], p["X_targ"], p["U_targ"], clock(), p["plant_op0"], p["plant_ops"],
+                p["Q"], p["R"], p["Qf"], p["sat"], p["du"])
+assert [shard_bounds(11, r, 2) for r in range(2)] == [(0, 6), (6, 11)]
+for final_only in (False, True):
+    got = mpc_batch_sharded(*args(), final_state_only=final_only)
+    if rank == 0:
+        ref = m4q.mpc_batch(*args())
+        xs = ref["xs"][:, :, -1:] if final_only else ref["xs"]
+        assert got["xs"].shape == xs.shape and np.array_equal(got["xs"], xs), ("xs", final_only)
+        for k in ("us", "exit_codes", "steps_done", "qp_solves"):
+            assert np.array_equal(got[k], ref[k]), (k, final_only)
+    else:
+        assert got is None
+dist.barrier()
+dist.destroy_process_group()
+print("rank %%d ok" %% rank)
+''' % root)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True) for r in range(2)]
+    outs = []
+    try:
+        for pr in procs:
+            outs.append(pr.communicate(timeout=600))
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    for r, (pr, (so, se)) in enumerate(zip(procs, outs)):
+        assert pr.returncode == 0 and ("rank %d ok" % r) in so, so[-2000:] + se[-4000:]
+
+
 def test_bench_line_schema():
     """bench.py prints ONE JSON line with the driver's contract fields, the roofline of the dominant kernel and the CPU baseline."""
     import json
