@@ -56,18 +56,46 @@ def plant_step_batch(x, u, op0, ops, dt, kind=_lib.PLANT_HAMILTONIAN):
 class QExperiment(Experiment):
     """Closed-system plant: H0 and H1_list are d x d Hermitian (ndarray or qutip.Qobj)."""
 
-    plant_kind = _lib.PLANT_HAMILTONIAN
-
     def __init__(self, H0, H1_list):
         super().__init__()
         self.H0 = _as_array(H0)
         self.H1_list = [_as_array(h) for h in H1_list]
+        self._me_args = {}
         self._sigma = 0
 
+    def set(self, key, value):
+        """Keyword argument of the reference's mesolve call (experiment.py:196-200).  The ones that change the ODE or its
+        output are honoured: 'c_ops' (collapse operators: the plant becomes the Lindblad generator, still exact per held
+        interval, still fused into the closed loop) and 'e_ops' (simulate returns expectation values, experiment.py:210).
+        Anything else ('options', 'args', 'progress_bar', ...) only tunes qutip's integrator and is kept but unused."""
+        self._me_args[key] = value
+
+    def _c_ops(self):
+        return [_as_array(c) for c in (self._me_args.get("c_ops") or [])]
+
+    @property
+    def plant_kind(self):
+        return _lib.PLANT_GENERATOR if self._c_ops() else _lib.PLANT_HAMILTONIAN
+
     def operators(self):
-        return self.H0, np.stack(self.H1_list)
+        """(op0, ops) for the device plant: the Hamiltonians, or with collapse operators the generators on vec_r(rho)
+        L0 = -i[H0, .] + sum_c (C . C^H - 1/2 {C^H C, .}),  L_k = -i[H_k, .]."""
+        cs = self._c_ops()
+        if not cs:
+            return self.H0, np.stack(self.H1_list)
+        from .vectorize import liouvillian
+        d = self.H0.shape[0]
+        eye = np.identity(d)
+        L0 = liouvillian(self.H0)
+        for c in cs:
+            cc = c.conj().T @ c
+            L0 = L0 + np.kron(c, c.conj()) - 0.5 * (np.kron(cc, eye) + np.kron(eye, cc.T))
+        return L0, np.stack([liouvillian(h) for h in self.H1_list])
 
     def f(self, t, x, u):
+        if self._c_ops():
+            L0, Lk = self.operators()
+            return (L0 + sum(l * uk for l, uk in zip(Lk, np.reshape(u, -1)))) @ np.reshape(x, -1)
         d = self.H0.shape[0]
         H = self.H0 + sum(h * uk for h, uk in zip(self.H1_list, np.reshape(u, -1)))
         rho = np.reshape(x, (d, d))
@@ -82,13 +110,19 @@ class QExperiment(Experiment):
         ts = np.asarray(ts, dtype=float)
         m = len(self.H1_list)
         x = np.reshape(np.asarray(x0, dtype=np.complex128), -1)
+        (op0, ops), kind = self.operators(), self.plant_kind
         cols = [x]
         for i in range(len(ts) - 1):
             u = np.reshape(us(ts[i]) if callable(us) else np.atleast_2d(us)[:, i], -1)[:m]
-            x = plant_step_batch(x[None], np.real(u)[None], self.H0, np.stack(self.H1_list), ts[i + 1] - ts[i])[0]
+            x = plant_step_batch(x[None], np.real(u)[None], op0, ops, ts[i + 1] - ts[i], kind)[0]
             cols.append(x)
         self.ts, self.us = ts, us
         self.xs = np.stack(cols, axis=1)
+        e_ops = self._me_args.get("e_ops")
+        if e_ops is not None:                                # np.array(res.expect): tr(E rho(t)), one row per operator
+            d = self.H0.shape[0]
+            rho = self.xs.T.reshape(-1, d, d)
+            self.xs = np.array([np.einsum('ij,tji->t', _as_array(e), rho) for e in e_ops])
         if self._sigma:
             noise = np.random.randn(*self.xs.shape) + 1j * np.random.randn(*self.xs.shape)
             return self.xs + noise * self._sigma
@@ -99,6 +133,9 @@ class LExperiment(QExperiment):
     """Open-system plant: x' = (L0 + sum_k u_k L_k) x with n x n generators on vec_r(rho)."""
 
     plant_kind = _lib.PLANT_GENERATOR
+
+    def operators(self):
+        return self.H0, np.stack(self.H1_list)
 
     def f(self, t, x, u):
         L = self.H0 + sum(h * uk for h, uk in zip(self.H1_list, np.reshape(u, -1)))

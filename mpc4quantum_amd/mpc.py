@@ -119,7 +119,8 @@ def iqp_line_search(Q_ls, R_ls, X_htarg, U_htarg, X_guess, U_guess, X_opt, U_opt
 def _native_plant(experiment):
     """True if the closed loop can stay on the GPU: one of this package's plants with identity lift/proj."""
     return (isinstance(experiment, QExperiment) and type(experiment).lift is Experiment.lift
-            and type(experiment).proj is Experiment.proj and not getattr(experiment, "_sigma", 0))
+            and type(experiment).proj is Experiment.proj and not getattr(experiment, "_sigma", 0)
+            and getattr(experiment, "_me_args", {}).get("e_ops") is None)
 
 
 def _trim(xs, us, code, done):

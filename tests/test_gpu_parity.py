@@ -358,6 +358,53 @@ def test_qexperiment_simulate_shape_and_values():
         assert rel(out[:, i + 1], x) <= 1e-12
 
 
+def test_qexperiment_collapse_and_expectation_operators():
+    """QExperiment.set('c_ops', ...) / set('e_ops', ...) (experiment.py:196-210): the Lindblad plant over held-control
+    intervals against scipy's expm of the generator; expectation values tr(E rho(t)) as mesolve's `expect`."""
+    import scipy.linalg
+    p = configs.build(3, batch=1)
+    a = np.diag([1.0, np.sqrt(2.0)], 1).astype(complex)           # transmon lowering operator
+    exp = m4q.QExperiment(p["plant_op0"][0], list(p["plant_ops"][0]))
+    exp.set("c_ops", [0.2 * a, 0.1 * (a.conj().T @ a)])            # relaxation + dephasing
+    ts = np.array([0.0, 0.25, 0.5, 0.75])
+    us = np.array([[0.3, -0.2, 0.5, 0.0], [0.1, 0.4, -0.3, 0.0]])
+    out = exp.simulate(p["x0"][0], ts, us)
+    assert out.shape == (9, 4)
+    L0, Lk = exp.operators()
+    x = p["x0"][0]
+    for i in range(3):
+        x = scipy.linalg.expm(0.25 * (L0 + us[0, i] * Lk[0] + us[1, i] * Lk[1])) @ x
+        assert rel(out[:, i + 1], x) <= 1e-12
+    assert np.abs(out[0] + out[4] + out[8] - 1).max() <= 1e-12       # trace
+    pops = [np.diag(np.eye(3)[k]).astype(complex) for k in range(3)]
+    exp.set("e_ops", pops)
+    ex = exp.simulate(p["x0"][0], ts, us)
+    assert ex.shape == (3, 4) and np.abs(ex - out[[0, 4, 8]]).max() <= 1e-15
+
+
+def test_mpc_with_collapse_operators_runs_fused_and_equals_the_generator_plant():
+    """mpc() with a QExperiment carrying c_ops: the closed loop stays on the GPU (generator plant) and equals, bit for bit, the
+    run with the same generators handed over as an LExperiment; a foreign-style host loop (one launch per step, simulate() on
+    the host) agrees to rounding."""
+    p = configs.build(1, batch=1)
+    sm = np.array([[0, 1], [0, 0]], dtype=complex)
+    qe = m4q.QExperiment(p["plant_op0"][0], list(p["plant_ops"][0]))
+    qe.set("c_ops", [np.sqrt(0.02) * sm])
+    L0, Lk = qe.operators()
+    le = m4q.LExperiment(L0, list(Lk))
+    outs = []
+    for exp in (qe, le):
+        clock = m4q.StepClock(p["dt"], p["horizon"], p["n_steps"])
+        model = m4q.DMDc(4, 4, 4, p["models"][0])
+        (xs, us), _, code = m4q.mpc(p["x0"][0], 1, 1, p["X_targ"], p["U_targ"], clock, exp, model, p["Q"], p["R"], p["Qf"],
+                                    sat=p["sat"], du=p["du"], progress_bar=False)
+        assert code == 0
+        outs.append((xs, us))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert abs(outs[0][0][0, -1] + outs[0][0][3, -1] - 1) < 1e-10           # trace preserved, purity not
+    assert abs(np.vdot(outs[0][0][:, -1], outs[0][0][:, -1]).real - 1) > 1e-4
+
+
 # ---------------------------------------------------------------- closed loop
 def _oracle_batch(p, idx, **kw):
     models = p["models"] if p["models"].shape[0] == 1 else p["models"][idx]

@@ -307,3 +307,38 @@ def test_streaming_dmdc_refits_vs_reference_golden(golden):
     assert d0.dim_u == 0 and d0.A.shape == (n, n)
     with pytest.raises(NotImplementedError):
         m4q.DMDc(n, n, k, A_boot).fit_iteration(Ys[:, 0], Xs[:, 0], Us[:, 0])
+
+
+def test_qexperiment_set_collapse_operators_gives_the_lindblad_generator():
+    """QExperiment.set (experiment.py:196-200): 'c_ops' turns the plant into the Lindblad generator on vec_r(rho); checked
+    against the master equation written out, trace preservation, and the Hamiltonian case (no c_ops) left untouched."""
+    from mpc4quantum_amd import _lib
+    from mpc4quantum_amd.experiment import QExperiment
+    rng = np.random.default_rng(11)
+    d = 3
+    def herm():
+        a = rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))
+        return a + a.conj().T
+    H0, H1 = herm(), [herm(), herm()]
+    exp = QExperiment(H0, H1)
+    assert exp.plant_kind == _lib.PLANT_HAMILTONIAN and exp.operators()[0].shape == (d, d)
+    cs = [0.3 * (rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))) for _ in range(2)]
+    exp.set("c_ops", cs)
+    exp.set("options", object())                              # integrator tuning: kept, unused
+    assert exp.plant_kind == _lib.PLANT_GENERATOR
+    L0, Lk = exp.operators()
+    assert L0.shape == (d * d, d * d) and Lk.shape == (2, d * d, d * d)
+    a = rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))
+    rho = a @ a.conj().T
+    rho /= np.trace(rho)
+    u = np.array([0.4, -0.7])
+    H = H0 + u[0] * H1[0] + u[1] * H1[1]
+    want = -1j * (H @ rho - rho @ H)
+    for c in cs:
+        cc = c.conj().T @ c
+        want = want + c @ rho @ c.conj().T - 0.5 * (cc @ rho + rho @ cc)
+    got = exp.f(0.0, rho.flatten(), u)
+    assert np.abs(got - want.flatten()).max() <= 1e-13
+    assert np.abs(np.identity(d).flatten() @ (L0 + u[0] * Lk[0] + u[1] * Lk[1])).max() <= 1e-13      # d/dt tr(rho) = 0
+    exp.set("c_ops", [])
+    assert exp.plant_kind == _lib.PLANT_HAMILTONIAN
