@@ -26,7 +26,8 @@ def test_executed_flops_and_compulsory_bytes():
 
 def test_counter_records_are_refused_when_stale(tmp_path, monkeypatch):
     b = _bench()
-    rec = {"config3_B65536_real_clip": {"traced_avg_launch_ms": 50.0, "counters": {"FETCH_SIZE": 1.0}}}
+    rec = {"config3_B65536_real_clip": {"traced_avg_launch_ms": 50.6, "hip_event_launch_ms_same_run": 50.0,
+                                        "counters": {"FETCH_SIZE": 1.0}}}
     path = tmp_path / "pmc.json"
     path.write_text(json.dumps(rec))
     monkeypatch.setattr(b, "PMC_JSON", str(path))
