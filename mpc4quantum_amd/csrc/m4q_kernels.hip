@@ -393,7 +393,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
     wave_sync();
     // exit code 3: non-finite objective (mpc.py:200-203).  exit code 2 (EXACT only): the solver gave up - the analogue of
     // the solver warning mpc.py:183-197 turns into code 2; either way the member's run ends here (mpc.py:196,203,231).
-    const bool fail = (M4Q_EXP & (64 | 128)) ? false : (!finite_d(chk) || capped);
+    const bool fail = (M4Q_EXP & (64 | 128 | 512)) ? false : (!finite_d(chk) || capped);
     if (solved) ++iter;
     double alpha = 1.0;
     bool fin = true;

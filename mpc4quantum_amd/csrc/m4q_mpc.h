@@ -668,10 +668,13 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
       for (int l = k; l < NU; ++l) {
         const S prod = cmul(BhP[k], Brow[l]);
         const S rkl = Rt[k * NU + l];
-        if (l == k) g[k][l] = mk(real_of(rkl) + rowsum<NX>(real_of(prod)), 0.0);
+        // (M4Q_EXP & 512: timing-only ablation, results wrong - no cross-lane sums in the sweep)
+        if constexpr ((M4Q_EXP & 512) != 0) g[k][l] = l == k ? mk(real_of(rkl) + real_of(prod) * real_of(prod), 0.0) : as_cplx(cadd(rkl, prod));
+        else if (l == k) g[k][l] = mk(real_of(rkl) + rowsum<NX>(real_of(prod)), 0.0);
         else g[k][l] = as_cplx(cadd(rkl, rowsum<NX>(prod)));
       }
-      h[k] = rowsum<NX>(cmul(cconj(Brow[k]), w));
+      if constexpr ((M4Q_EXP & 512) != 0) h[k] = cmul(cconj(Brow[k]), w);
+      else h[k] = rowsum<NX>(cmul(cconj(Brow[k]), w));
     }
     // Hh[l] = (B^H P A_t)[l][j] = sum_i BhP[l][i] A_t[i][j]
     S Hh[NU];
