@@ -45,6 +45,16 @@ int fail(int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(-(int)e_, "%s: %s", #expr, hipGetErrorString(e_));       \
   } while (0)
 
+// inside m4q_session_create, once the session object exists: a failing HIP call must not leak it
+#define HIP_TRY_OWNED(sess, expr)                                                              \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      m4q_session_destroy(sess);                                                               \
+      return fail(-(int)e_, "%s: %s", #expr, hipGetErrorString(e_));                           \
+    }                                                                                          \
+  } while (0)
+
 const m4q::ShapeOps* find_shape(int nx, int nu, int order) {
   static const m4q::ShapeOps* table[] = {
 #define M4Q_SHAPE(nx, nu, ord) m4q_shape_##nx##_##nu##_##ord(),
@@ -250,10 +260,10 @@ int m4q_session_create(const m4q_problem* p, int32_t B, int32_t device, m4q_sess
     delete s;
     return fail(M4Q_E_UNSUPPORTED, "dim_x=%d is not a vectorised density matrix: no device plant (use M4Q_PLANT_NONE)", p->dim_x);
   }
-  HIP_TRY(hipGetDevice(&s->device));
-  HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-  HIP_TRY(hipEventCreate(&s->ev0));
-  HIP_TRY(hipEventCreate(&s->ev1));
+  HIP_TRY_OWNED(s, hipGetDevice(&s->device));
+  HIP_TRY_OWNED(s, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  HIP_TRY_OWNED(s, hipEventCreate(&s->ev0));
+  HIP_TRY_OWNED(s, hipEventCreate(&s->ev1));
   const size_t n = p->dim_x, m = p->dim_u, P = sh->np, T = p->horizon, ns = p->n_steps, cols = p->target_cols;
   const size_t k = p->plant_kind == M4Q_PLANT_GENERATOR ? n : (size_t)sh->d;
   const size_t C = 16;
@@ -278,7 +288,7 @@ int m4q_session_create(const m4q_problem* p, int32_t B, int32_t device, m4q_sess
   for (int i = 0; i < M4Q_F_COUNT && !rc; ++i) rc = s->f[i].alloc(fb[i]);
   // resident grid: as many workgroups as the device holds at once (persistent, quad-strided)
   hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, s->device));
+  HIP_TRY_OWNED(s, hipGetDeviceProperties(&prop, s->device));
   // the grid (and the per-row workspace) is sized for whichever path keeps more workgroups resident
   const int exact = (p->qp_flags & M4Q_QP_EXACT_BOX) ? 1 : 0;
   int per_cu = std::max(sh->occupancy(p->plant_kind, 0, exact), s->force_complex ? 0 : sh->occupancy(p->plant_kind, 1, exact));
@@ -303,8 +313,8 @@ int m4q_session_create(const m4q_problem* p, int32_t B, int32_t device, m4q_sess
   if (!rc) rc = s->Wls.alloc((4 * n + 2 * m) * 8);
   if (rc) { m4q_session_destroy(s); return rc; }
   for (int i : {M4Q_F_XS, M4Q_F_US, M4Q_F_CODES, M4Q_F_STEPS_DONE, M4Q_F_QP_SOLVES})
-    HIP_TRY(hipMemsetAsync(s->f[i].p, 0, fb[i], s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY_OWNED(s, hipMemsetAsync(s->f[i].p, 0, fb[i], s->stream));
+  HIP_TRY_OWNED(s, hipStreamSynchronize(s->stream));
   *out = s;
   return 0;
 }
