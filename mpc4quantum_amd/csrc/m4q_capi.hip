@@ -339,6 +339,7 @@ static int check_watchdog(m4q_session* s) {
   s->launched = false;
   int flag = 0;
   HIP_TRY(hipMemcpy(&flag, (const char*)s->queue.p + 4, 4, hipMemcpyDeviceToHost));
+  if (flag) HIP_TRY(hipMemset((char*)s->queue.p + 4, 0, 4));
   if (flag)
     return fail(M4Q_E_TIMEOUT, "the closed-loop kernel abandoned the launch: its watchdog expired (M4Q_KERNEL_TIMEOUT_S, default 300 s "
                                "of device time) before every ensemble member had finished; this launch's results are not valid");
@@ -543,7 +544,13 @@ int m4q_session_run(m4q_session* s, int32_t step_begin, int32_t step_end) {
     }
     a.deadline_ticks = (unsigned long long)(seconds * 1e8);  // s_memrealtime counts at 100 MHz
   }
-  HIP_TRY(hipMemsetAsync(s->queue.p, 0, 64, s->stream));
+  if (s->launched) {
+    // an earlier launch has not been synchronised yet: its watchdog flag (bytes 4..8) must survive until check_watchdog reads it
+    HIP_TRY(hipMemsetAsync(s->queue.p, 0, 4, s->stream));
+    HIP_TRY(hipMemsetAsync((char*)s->queue.p + 8, 0, 56, s->stream));
+  } else {
+    HIP_TRY(hipMemsetAsync(s->queue.p, 0, 64, s->stream));
+  }
   HIP_TRY(hipMemsetAsync(s->head_done.p, 0, (size_t)s->B * 4, s->stream));
   if (step_begin == 0) {
     HIP_TRY(hipMemsetAsync(s->f[M4Q_F_QP_SOLVES].p, 0, s->fbytes[M4Q_F_QP_SOLVES], s->stream));

@@ -1375,5 +1375,15 @@ def test_kernel_watchdog_turns_a_launch_that_does_not_end_into_an_error(monkeypa
         sess.run()                                             # the session stays usable
         res = sess.results()
         assert np.all(res["exit_codes"] == 0) and np.all(res["steps_done"] == 6)
+        # a launch queued behind the abandoned one must not wipe its flag before the host has looked
+        monkeypatch.setenv("M4Q_KERNEL_TIMEOUT_S", "1e-7")
+        sess.run()
+        monkeypatch.delenv("M4Q_KERNEL_TIMEOUT_S")
+        sess.run()
+        with pytest.raises(_lib.M4qError) as err:
+            sess.sync()
+        assert err.value.code == _lib.E_TIMEOUT
+        sess.run()
+        assert np.all(sess.results()["steps_done"] == 6)
     finally:
         sess.close()
