@@ -1009,6 +1009,22 @@ def test_repeated_launches_are_bit_identical(kw):
                     assert np.array_equal(res[key], first[key]), key
     finally:
         sess.close()
+    # ... and with the build that stored tests/golden/gpu_checksums.json: an optimisation that changes a rounding anywhere in the
+    # loop shows up here and has to be accepted on purpose (parity tests green, then M4Q_STORE_CHECKSUMS=<file> to re-take).
+    import hashlib
+    import json
+    h = hashlib.sha256()
+    for key in ("xs", "us", "qp_solves"):
+        h.update(np.ascontiguousarray(first[key]).tobytes())
+    name = "config3_B4096_" + ("exact" if kw.get("exact_qp") else "clip") + ("_complex" if kw.get("force_complex") else "_real")
+    store = os.environ.get("M4Q_STORE_CHECKSUMS")
+    if store:
+        have = json.load(open(store)) if os.path.exists(store) else {}
+        have[name] = h.hexdigest()
+        json.dump(have, open(store, "w"), indent=1, sort_keys=True)
+        return
+    stored = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gpu_checksums.json")))
+    assert stored[name] == h.hexdigest(), "results of %s differ bit-wise from the build that stored the checksum" % name
 
 
 # ---------------------------------------------------------------- the closed loop against the REFERENCE's own mpc.py
