@@ -281,6 +281,10 @@ def loop_cases():
     cases["qubit_o1_inf_step0"] = dict(qubit, order=1, T=10, n_steps=5, x0_scale=1e200)
     cases["qubit_o1_inf_later"] = dict(qubit, order=1, T=10, n_steps=12, growth=60.0)
     cases["qubit_o1_nan"] = dict(qubit, order=1, T=10, n_steps=3, x0_scale=np.nan)
+    # streaming=True (mpc.py:281-285) with the reference's OnlineDMDc: the model object is refitted after every step, the loop keeps
+    # linearising the operators extracted at entry (model.A is rebound, the views WrapModel holds go stale), and with measure_freq = 2
+    # the refitted model DOES predict the unmeasured states (mpc.py:261-267)
+    cases["qubit_o1_streaming_mf2"] = dict(qubit, order=1, T=10, n_steps=10, measure_freq=2, streaming=True, alpha=1e-2)
     # transmon (test_mpc4quantum.py:504-564, util_qubits.py:92-111): model anharmonicity 5 % off the plant's
     dt = 0.25
     alpha = -2 * np.pi * 0.1 / dt
@@ -360,7 +364,10 @@ def golden_mpc_loop():
         n = d * d
         A_dst = vec.discretize_homogeneous([liou(H) for H in c["H_model"]], dt, order)
         P = lin.size_of_library(order, m) - 1
-        model = mdl.DMDc(n, n, n * P, A_dst)
+        if c.get("streaming"):
+            model = mdl.OnlineDMDc.from_bootstrap(n, n, n * P, A_dst.copy(), alpha=c["alpha"])
+        else:
+            model = mdl.DMDc(n, n, n * P, A_dst)
         clock = rmpc.StepClock(dt, T, ns)
         clock.measure_freq = c.get("measure_freq", 1)
         plant = HeldPlant(c["H_plant"][0], c["H_plant"][1:], c.get("growth", 0.0))
@@ -383,6 +390,7 @@ def golden_mpc_loop():
         out[k + "warm_start"] = np.array(bool(c.get("warm_start", True)))
         out[k + "max_iter"] = np.array(c.get("max_iter", 100))
         out[k + "growth"] = np.array(c.get("growth", 0.0))
+        out[k + "streaming"], out[k + "alpha"] = np.array(bool(c.get("streaming", False))), np.array(c.get("alpha", 0.0))
         out[k + "exit_index"], out[k + "exit_thr"] = np.array(c.get("exit_index", -1)), np.array(c.get("exit_thr", 0.0))
         out[k + "model"], out[k + "x0"] = A_dst, x0
         out[k + "H_plant"] = np.stack(c["H_plant"])
@@ -394,11 +402,13 @@ def golden_mpc_loop():
                 warnings.simplefilter("ignore")
                 (xs, us), _, code = rmpc.mpc(x0, m, order, X_targ, U_targ, clock, plant, model, Q, R, Q, sat=c["sat"],
                                              du=c["du"], max_iter=c.get("max_iter", 100), exit_condition=exit_condition,
-                                             warm_start=c.get("warm_start", True), progress_bar=False)
+                                             warm_start=c.get("warm_start", True), progress_bar=False,
+                                             streaming=bool(c.get("streaming", False)))
         except Exception as e:                                       # a NaN state: numpy.linalg.pinv raises inside lqr.py:61
             raised = type(e).__name__
             xs, us, code = np.zeros((n, 0)), None, -1
         out[k + "raised"] = np.array(raised)
+        out[k + "model_final"] = np.array(model.A)
         out[k + "xs"] = xs
         out[k + "us"] = us if us is not None else np.zeros((m, 0))
         out[k + "us_is_none"] = np.array(us is None)

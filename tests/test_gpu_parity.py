@@ -1052,8 +1052,10 @@ def _ref_plant(c):
     return m4q.QExperiment(H[0], list(H[1:]))
 
 
-def _ref_mpc(c, **kw):
+def _ref_mpc(c, model=None, **kw):
     n = c["d"] ** 2
+    if model is None:
+        model = m4q.DMDc(n, n, c["model"].shape[1] - n, c["model"])
     clock = m4q.StepClock(c["dt"], c["T"], c["n_steps"])
     clock.measure_freq = c["measure_freq"]
     cond = None
@@ -1063,7 +1065,7 @@ def _ref_mpc(c, **kw):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         (xs, us), _, code = m4q.mpc(c["x0"], c["m"], c["order"], c["X_targ"], c["U_targ"], clock, _ref_plant(c),
-                                    m4q.DMDc(n, n, c["model"].shape[1] - n, c["model"]), c["Q"], c["R"], c["Q"], sat=c["sat"],
+                                    model, c["Q"], c["R"], c["Q"], sat=c["sat"],
                                     du=c["du"], max_iter=c["max_iter"], exit_condition=cond, warm_start=c["warm_start"],
                                     progress_bar=False, qp_flags=_lib.QP_REF_LQR, **kw)
     return xs, us, code, clock
@@ -1120,6 +1122,20 @@ def test_mpc_dropin_free_running_vs_reference_mpc_py(golden, name):
     assert np.array_equal(clock.ts_sim, c["ts_sim"])
     assert rel(us[:, :2], c["us"][:, :2]) <= 1e-10 and rel(xs[:, :3], c["xs"][:, :3]) <= 1e-10
     assert rel(us, c["us"]) <= 1e-5 and rel(xs, c["xs"]) <= 1e-5
+
+
+def test_mpc_dropin_streaming_vs_reference_mpc_py(golden):
+    """mpc(streaming=True) around OnlineDMDc with measure_freq = 2 against the reference's mpc() around ITS OnlineDMDc
+    (mpc.py:261-267, 281-285): states, controls, and the model object the call hands back."""
+    c = _ref_case(golden("mpc_loop"), "qubit_o1_streaming_mf2")
+    n = c["d"] ** 2
+    model = m4q.OnlineDMDc.from_bootstrap(n, n, c["model"].shape[1] - n, c["model"].copy(), alpha=float(c["alpha"]))
+    xs, us, code, clock = _ref_mpc(c, model=model, streaming=True)
+    assert code == int(c["exit_code"]) == 0 and xs.shape == c["xs"].shape and us.shape == c["us"].shape
+    assert np.array_equal(clock.ts_sim, c["ts_sim"])
+    assert rel(us[:, :2], c["us"][:, :2]) <= 1e-10 and rel(xs[:, :3], c["xs"][:, :3]) <= 1e-10
+    assert rel(us, c["us"]) <= 1e-5 and rel(xs, c["xs"]) <= 1e-5
+    assert np.abs(c["model_final"] - c["model"]).max() > 1e-3 and np.abs(model.A - c["model_final"]).max() <= 1e-6
 
 
 @pytest.mark.parametrize("name", ["qubit_o1_exit_step3", "qubit_o1_exit_step0"])

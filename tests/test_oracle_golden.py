@@ -195,10 +195,11 @@ def loop_case(g, name):
     return c
 
 
-def oracle_loop(c, **kw):
+def oracle_loop(c, model=None, **kw):
     """The oracle's loop (qp_mode "lqr" = the arithmetic of lqr.py) on a golden scenario."""
     n = c["d"] ** 2
-    model = orc.OracleDMDc(n, n, c["model"].shape[1] - n, c["model"])
+    if model is None:
+        model = orc.OracleDMDc(n, n, c["model"].shape[1] - n, c["model"])
     clock = orc.OracleClock(c["dt"], c["T"], c["n_steps"])
     clock.measure_freq = c["measure_freq"]
     H = c["H_plant"]
@@ -289,6 +290,29 @@ def test_mpc_loop_exit_condition_vs_reference_mpc_py(golden, name):
     else:
         assert us.shape == c["us"].shape and np.abs(us - c["us"]).max() <= 1e-10
     assert np.array_equal(clock.ts_sim, c["ts_sim"])
+
+
+def test_mpc_loop_streaming_vs_reference_mpc_py(golden):
+    """streaming=True around the reference's OnlineDMDc with measure_freq = 2 (mpc.py:261-267, 281-285): the model object is
+    refitted after every step and predicts the unmeasured states, while the loop keeps linearising the operators extracted at
+    entry (fit_iteration rebinds model.A; the views WrapModel took at mpc.py:156 go stale).  The refit class used here is the
+    package's host-side OnlineDMDc, itself pinned against the reference's by dmdc.npz."""
+    from mpc4quantum_amd.model import OnlineDMDc
+    c = loop_case(golden("mpc_loop"), "qubit_o1_streaming_mf2")
+    assert bool(c["streaming"]) and c["measure_freq"] == 2
+    n = c["d"] ** 2
+    model = OnlineDMDc.from_bootstrap(n, n, c["model"].shape[1] - n, c["model"].copy(), alpha=float(c["alpha"]))
+    tr = []
+    xs, us, code, clock = oracle_loop(c, model=model, streaming=True, solve_trace=tr)
+    assert code == int(c["exit_code"]) == 0 and xs.shape == c["xs"].shape and us.shape == c["us"].shape
+    assert np.array_equal(np.array([s_k for s_k, _, _ in tr]), c["solve_step"])
+    assert np.abs(us[:, :2] - c["us"][:, :2]).max() <= 1e-10 and np.abs(xs[:, :3] - c["xs"][:, :3]).max() <= 1e-10
+    assert np.abs(us - c["us"]).max() <= 1e-6 * c["sat"] and np.abs(xs - c["xs"]).max() <= 1e-6
+    assert np.abs(c["model_final"] - c["model"]).max() > 1e-3                      # the reference's model did move ...
+    assert np.abs(model.A - c["model_final"]).max() <= 1e-6                          # ... and this one moved with it
+    # the refit steers nothing but the predictions: the same run without streaming applies the same controls at measured steps
+    xs2, us2, _, _ = oracle_loop(c)
+    assert np.abs(us2[:, 0] - us[:, 0]).max() <= 1e-12 and np.abs(xs2[:, 1] - xs[:, 1]).max() <= 1e-12
 
 
 def test_mpc_loop_infinite_objective_vs_reference_mpc_py(golden):
