@@ -132,6 +132,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
   cost.Q = ldsQ; cost.Qf = ldsQ + NX * NX; cost.q_stride = 0; cost.R = ldsQ + 2 * NX * NX; cost.r_stride = 0;
   // workspace of this resident row: wave-uniform base per workgroup, lane part = row within the wave
   const unsigned sX = (unsigned)(T + 1) * NX, sU = (unsigned)T * NU, sG = (unsigned)T * (NX + 1) * NU;
+  // Lanes NX..15 of a row own no column (7 of 16 at d = 3, 12 of 16 at d = 2) and run the sweeps on a copy of column NX-1's data.
+  // -DM4Q_MASK_IDLE=1 turns EXEC off for them during the two sweeps (every DPP source is a lane < NX; results bit-identical, all
+  // GPU tests pass).  Tried in the hope that idle fp64 lanes cost clock: they do not - config 5's share and the complex path run
+  // at the same speed, config 3 gains 1.4 % from a different register allocation (profiles/r02_ab_experiments.txt).  Off.
+#ifndef M4Q_MASK_IDLE
+#define M4Q_MASK_IDLE 0
+#endif
+  constexpr bool MASK_IDLE = M4Q_MASK_IDLE && NX < 16 && !EXACT;
 #ifndef M4Q_WD_LDS
 #define M4Q_WD_LDS 1
 #endif
@@ -314,7 +322,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
       //  n = 16 only: config 4 85.5 -> 84.2 ms; at n = 9 the kernel with both instantiations is SLOWER, 50.65 -> 51.7 ms,
       //  although it executes 27 vector instructions fewer per horizon index - profiles/r02_ab_experiments.txt)
       if (M4Q_TARG_CONST && NX == 16 && (a.flags & QP_TARG_CONST)) riccati_backward<S, NX, NU, FusedProv<S, NX, NU, ORDER>, false, true>(prov, T, win, cost, a.flags, gains, j, st);
-      else riccati_backward<S, NX, NU>(prov, T, win, cost, a.flags, gains, j, st);
+      else if (!MASK_IDLE || lane_ok) riccati_backward<S, NX, NU>(prov, T, win, cost, a.flags, gains, j, st);
     }
     wave_sync();
     double uapp[NU];
@@ -386,9 +394,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
         }
       }
     } else {
-      if constexpr (!(M4Q_EXP & 4))
-        chk = rollout_forward<S, NX, NU, false>(prov, T, x_cur, win, cost, a.flags, gains, a.sat, lo0, hi0, Xo, Uo, j, st, uapp,
-                                                !use_ls, &Xg, &Ug);
+      if constexpr (!(M4Q_EXP & 4)) {
+        if (!MASK_IDLE || lane_ok)
+          chk = rollout_forward<S, NX, NU, false>(prov, T, x_cur, win, cost, a.flags, gains, a.sat, lo0, hi0, Xo, Uo, j, st, uapp,
+                                                  !use_ls, &Xg, &Ug);
+        if constexpr (MASK_IDLE) {
+          // the row's scalars back into the lanes that sat the sweep out
+          chk = bcast<0>(chk);
+#pragma unroll
+          for (int k = 0; k < NU; ++k) uapp[k] = bcast<0>(uapp[k]);
+        }
+      }
     }
     wave_sync();
     // exit code 3: non-finite objective (mpc.py:200-203).  exit code 2 (EXACT only): the solver gave up - the analogue of
