@@ -132,13 +132,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
   cost.Q = ldsQ; cost.Qf = ldsQ + NX * NX; cost.q_stride = 0; cost.R = ldsQ + 2 * NX * NX; cost.r_stride = 0;
   // workspace of this resident row: wave-uniform base per workgroup, lane part = row within the wave
   const unsigned sX = (unsigned)(T + 1) * NX, sU = (unsigned)T * NU, sG = (unsigned)T * (NX + 1) * NU;
-  // Lanes NX..15 of a row own no column (7 of 16 at d = 3, 12 of 16 at d = 2) and run the sweeps on a copy of column NX-1's data.
-  // -DM4Q_MASK_IDLE=1 turns EXEC off for them during the two sweeps (every DPP source is a lane < NX; results bit-identical, all
-  // GPU tests pass).  Tried in the hope that idle fp64 lanes cost clock: they do not - config 5's share and the complex path run
-  // at the same speed, config 3 gains 1.4 % from a different register allocation (profiles/r02_ab_experiments.txt).  Off.
-#ifndef M4Q_MASK_IDLE
-#define M4Q_MASK_IDLE 0
-#endif
+  // Lanes NX..15 of a row own no column (7 of 16 at d = 3, 12 of 16 at d = 2).  Left enabled they run the sweeps on a copy of
+  // column NX-1's data: harmless for the results, but the fp64 pipe spends power on them, and the clock this chip holds under an
+  // fp64-dense load follows the power.  EXEC is therefore off for them during the two sweeps (every DPP source is a lane < NX;
+  // results bit-identical): the complex path runs at 2.30 GHz instead of 2.04 (133.3 -> 117.6 ms, config 3), the real path at 2.29
+  // instead of 2.18 (51.2 -> 50.4 ms; config 5's share 171.2 -> 166.3 ms).  profiles/r02_ab_experiments.txt, r02_clock_ramp.txt.
   constexpr bool MASK_IDLE = M4Q_MASK_IDLE && NX < 16 && !EXACT;
 #ifndef M4Q_WD_LDS
 #define M4Q_WD_LDS 1

@@ -19,6 +19,9 @@
 #ifndef M4Q_FWD_BATCH
 #define M4Q_FWD_BATCH 1      // rollout: the row form read in one batch (51.2 -> 50.85 ms)
 #endif
+#ifndef M4Q_MASK_IDLE
+#define M4Q_MASK_IDLE 1      // lanes that own no column sit the two sweeps out (EXEC off): less power, higher clock (m4q_kernels.hip)
+#endif
 #ifndef M4Q_TARG_CONST
 #define M4Q_TARG_CONST 1     // constant targets: A_t xbar from 1 + NP products formed once per sweep
 #endif
