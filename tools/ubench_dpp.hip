@@ -14,10 +14,21 @@
 // MODE 4: as MODE 1 with an s_nop 1 in front of every 4
 // MODE 5: as MODE 2 with an s_nop 1 in front of every 4 (the cmac block of the kernel: re, im, re, im)
 // MODE 6: v_mov_b64_dpp + plain fma (unfused broadcast)
+// lanes: only lanes (threadIdx.x & 15) < lanes of every 16-lane row take part (EXEC off for the others) - the `ubench_dpp lanes` mode
 template <int MODE>
-__global__ __launch_bounds__(64) void k(double* out, int iters) {
+__global__ __launch_bounds__(64) void k(double* out, int iters, int lanes) {
   double a0 = threadIdx.x * 1e-9, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
   double x = 1.0000001, y = 0.9999999;
+  if (lanes < 0) {
+    // `lanes` mode with data that toggles: every lane its own full-mantissa operands (a hash of the lane and workgroup), so that the
+    // multiplier arrays see different bits in neighbouring lanes and from one accumulator to the next
+    lanes = -lanes;
+    unsigned long long h = (threadIdx.x + 64ull * blockIdx.x + 1) * 0x9E3779B97F4A7C15ull;
+    auto next = [&]() { h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32; return 0.5 + (double)(h >> 11) * (1.0 / 9007199254740992.0); };
+    x = next(); y = -next() * 1e-9;
+    a0 = next(); a1 = next(); a2 = next(); a3 = next(); a4 = next(); a5 = next(); a6 = next(); a7 = next();
+  }
+  if ((int)(threadIdx.x & 15) < lanes)
   for (int i = 0; i < iters; ++i) {
     if constexpr (MODE == 0) {
       asm volatile(R16("v_fma_f64 %0, %8, %9, %0\n\tv_fma_f64 %1, %8, %9, %1\n\tv_fma_f64 %2, %8, %9, %2\n\tv_fma_f64 %3, %8, %9, %3\n\t"
@@ -57,16 +68,16 @@ __global__ __launch_bounds__(64) void k(double* out, int iters) {
 }
 
 template <int MODE>
-void run(const char* name, int waves_per_simd, int iters = 2000) {
+void run(const char* name, int waves_per_simd, int iters = 2000, int lanes = 16) {
   const int grid = 256 * 4 * waves_per_simd;
   double* d;
   hipMalloc(&d, (size_t)grid * 64 * 8);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(64), 0, 0, d, iters);
+  hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(64), 0, 0, d, iters, lanes);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(64), 0, 0, d, iters);
+  hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(64), 0, 0, d, iters, lanes);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms;
@@ -79,6 +90,19 @@ void run(const char* name, int waves_per_simd, int iters = 2000) {
 }
 
 int main(int argc, char** argv) {
+  if (argc > 1 && argv[1][0] == 'l' && argv[1][1] == 'a') {
+    // `ubench_dpp lanes`: the sustained stream with 16, 9 and 4 of every 16 lanes enabled.  The instruction stream is the same; if
+    // the launch gets shorter with fewer live lanes, the clock the chip holds under fp64 load follows the power of the lanes at work
+    for (int rep = 0; rep < 2; ++rep)
+      for (int lanes : {16, 9, 4}) {
+        char name[96];
+        snprintf(name, sizeof name, "SUSTAINED v_fmac_f64_dpp x8, %2d of 16 lanes live", lanes);
+        run<1>(name, 2, 300000, lanes);
+        snprintf(name, sizeof name, "SUSTAINED same, per-lane random operands, %2d of 16", lanes);
+        run<1>(name, 2, 300000, -lanes);
+      }
+    return 0;
+  }
   if (argc > 1) {
     // `ubench_dpp long`: launches of ~0.1-0.2 s - the rate the chip SUSTAINS once its clock has settled under an fp64-dense load
     // (the 1 ms launches below finish before it does)
