@@ -159,31 +159,24 @@ def main():
     ap.add_argument("--cpu-cores", type=int, default=0, help="host cores for the CPU baseline (0 = all this job may use: affinity "
                                                              "mask cut to the cgroup CPU quota)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="time budget of every CPU-baseline worker")
-    ap.add_argument("--backend", default="nccl", help="collective backend for N > 1: nccl (= RCCL over xGMI, the real thing) or "
-                                                      "gloo (rehearsal on a box with fewer GPUs than ranks: results staged through the host)")
     ap.add_argument("--exact-qp", action="store_true", help="not the headline: every QP solved to the box-constrained optimum "
                                                             "(M4Q_QP_EXACT_BOX); roofline flops then count pinned sweeps")
-    ap.add_argument("--force-dist", action="store_true", help="rehearsal: take the N > 1 code path (process group, torch-owned "
-                                                              "output buffers, gather) even with one rank")
+    ap.add_argument("--force-dist", action="store_true", help="rehearsal: take the N > 1 code path (RCCL communicator, gather "
+                                                              "buffers bound to the session, one gather per run) even with one rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    torch = None
     multi = world > 1 or args.force_dist
+    comm = None
+    dev_index = -1
     if multi:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        ndev = torch.cuda.device_count()
-        dev_index = local_rank if args.backend == "nccl" else local_rank % max(ndev, 1)
-        torch.cuda.set_device(dev_index)
-        if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend="gloo")
+        # one process per GPU; RCCL through the C ABI (m4q_comm_*): no PyTorch in the product path.  The launcher has set
+        # RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT; the unique id travels through a file keyed by this launch.
+        from mpc4quantum_amd.distributed import RcclComm
+        dev_index = local_rank
+        comm = RcclComm.from_env(device=dev_index)
 
     import numpy as np
     from mpc4quantum_amd import _lib, configs
@@ -201,12 +194,13 @@ def main():
                            target_cols=ns + T + 1, device=dev_index if multi else -1, exact_qp=args.exact_qp)
     shard = None
     if multi:
-        # the product's multi-GPU path (mpc4quantum_amd/distributed.py): the session's outputs are bound into ONE torch-owned
-        # device buffer [final states | us | codes | steps done | solve counts] and one RCCL gather moves it
-        # Two such buffers alternate: the gather of run k travels while the kernel of run k+1 computes (every run's
-        # gather is inside the timed region; the last one is waited for at the closing fence).
+        # the product's multi-GPU path (mpc4quantum_amd/distributed.py): the session's outputs are bound into ONE library-owned
+        # device buffer [final states | us | codes | steps done | solve counts | status] and one RCCL gather moves it, enqueued
+        # behind the kernel on the communicator's stream.  Two such buffers alternate: the gather of run k travels while the
+        # kernel of run k+1 computes (every run's gather is inside the timed region; the last one is waited for at the
+        # closing fence).
         from mpc4quantum_amd.distributed import ShardedResults
-        shard = [ShardedResults(sess, B, dst=0, final_state_only=True) for _ in range(2)]
+        shard = [ShardedResults(sess, B, comm, dst=0, final_state_only=True, slot=i) for i in range(2)]
     if per_model:
         sess.build_models(p["dt"], p["generators"], p["scales"])
         models = None
@@ -229,13 +223,14 @@ def main():
             sess.run(0, ns)
 
     def fence():
+        # barrier + device drained on both sides of the timed region (the contract's barrier + synchronize)
         sess.sync()
         if multi:
             for sh in shard:
                 sh.wait()
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+            comm.wait()
+            comm.barrier()
+            sess.sync()
 
     for _ in range(args.warmup):
         one_step()
@@ -253,14 +248,10 @@ def main():
     ok = int((res["exit_codes"] == 0).sum())
     info = sess.info()
     if multi:
-        t = torch.tensor([elapsed, float(units_per_step), float(ok)], dtype=torch.float64,
-                         device="cuda" if args.backend == "nccl" else "cpu")
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        elapsed = float(tmax[0])
-        units_total = float(t[1])
-        ok_total = int(t[2])
+        elapsed = float(comm.allreduce([elapsed], "max")[0])               # MAX over ranks of the timed region
+        tot = comm.allreduce([float(units_per_step), float(ok)], "sum")
+        units_total = float(tot[0])
+        ok_total = int(tot[1])
     else:
         units_total = float(units_per_step)
         ok_total = ok
@@ -332,9 +323,12 @@ def main():
             cores = args.cpu_cores or usable_cores()
             out["cpu_baseline"] = cpu_baseline(args.config, p, cores, args.cpu_seconds)
         print(json.dumps(out))
+    if multi:
+        for sh in shard:
+            sh.close()
     sess.close()
     if multi:
-        dist.destroy_process_group()
+        comm.close()
 
 
 if __name__ == "__main__":

@@ -203,6 +203,45 @@ M4Q_API int m4q_session_path(const m4q_session* s);
 M4Q_API int m4q_session_qp_stats(m4q_session* s, int64_t* out6);
 /* resident bytes and launch geometry, for reports */
 M4Q_API int m4q_session_info(const m4q_session* s, int64_t* hbm_bytes, int32_t* grid, int32_t* lds_bytes);
+/* final-state-only results: copy xs[:, n_steps, :] of the session's state history into dst_dev [B][n] c (device memory),
+ * enqueued on the session stream behind the launches queued so far */
+M4Q_API int m4q_session_copy_final_state(m4q_session* s, void* dst_dev);
+/* the watchdog flag (0 / 1, int32) of the launches queued so far into dst_dev (device memory), on the session stream: the
+ * status word of a gather buffer, so that the gathering rank sees M4Q_E_TIMEOUT of any rank in the bytes it receives */
+M4Q_API int m4q_session_copy_status(m4q_session* s, void* dst_dev);
+
+/* ---- ensemble sharding over the GPUs of one node: one process per GPU, ONE gather of results at the end ----------
+ * The reference has no counterpart: mpc4quantum/mpc.py:128-304 runs one closed loop and has no cross-instance data
+ * flow, which is exactly why an ensemble shards with no collective on the data path.  The communicator is RCCL
+ * (librccl.so, loaded on first use) over xGMI; the unique id travels between the processes by whatever the launcher
+ * offers (mpc4quantum_amd/distributed.py: a file keyed by the launcher's MASTER_PORT). */
+typedef struct m4q_comm m4q_comm;
+#define M4Q_UNIQUE_ID_BYTES 128
+#define M4Q_E_COMM (-1005) /* librccl.so missing, or an RCCL call failed (m4q_last_error() has ncclGetErrorString) */
+
+/* rank 0: a fresh RCCL unique id (ncclGetUniqueId), id128 = M4Q_UNIQUE_ID_BYTES caller-owned bytes */
+M4Q_API int m4q_comm_unique_id(void* id128);
+/* every rank, same id: ncclCommInitRank on `device` (< 0: the current one); collective - returns when all ranks joined */
+M4Q_API int m4q_comm_create(int32_t rank, int32_t world, const void* id128, int32_t device, m4q_comm** out);
+M4Q_API void m4q_comm_destroy(m4q_comm* c);
+/* the one collective of a job: ncclGather of `bytes` bytes from every rank's send_dev into recv_dev on rank dst
+ * (world * bytes there; ignored elsewhere).  Enqueued on the communicator's own stream BEHIND everything queued so far
+ * on `after`'s stream (after may be NULL), so the kernel that fills send_dev needs no host synchronisation; `slot`
+ * (0..7) names the completion event m4q_comm_wait blocks on - two buffers can alternate so that the gather of run k
+ * travels under the kernel of run k+1. */
+M4Q_API int m4q_comm_gather(m4q_comm* c, m4q_session* after, const void* send_dev, void* recv_dev, size_t bytes, int32_t dst,
+                            int32_t slot);
+/* host blocks until the gather last enqueued under `slot` has completed (slot < 0: every collective enqueued so far) */
+M4Q_API int m4q_comm_wait(m4q_comm* c, int32_t slot);
+/* small host-side reductions for reports and fences (op 0 = sum, 1 = max) over n <= 64 doubles, in place;
+ * n = 0 is a barrier.  Blocks until done. */
+M4Q_API int m4q_comm_allreduce_f64(m4q_comm* c, double* inout_host, int32_t n, int32_t op);
+
+/* device memory owned by the library (gather buffers): zero-filled; device < 0 = the current one */
+M4Q_API int m4q_device_alloc(size_t bytes, int32_t device, void** out);
+M4Q_API int m4q_device_free(void* dev);
+M4Q_API int m4q_device_read(void* host, const void* dev, size_t bytes);  /* blocking device -> host copy */
+M4Q_API int m4q_device_write(void* dev, const void* host, size_t bytes); /* blocking host -> device copy */
 
 #ifdef __cplusplus
 }

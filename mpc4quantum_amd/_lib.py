@@ -17,7 +17,8 @@ QP_DU_BAND = 2
 QP_EXACT_BOX = 4
 OPT_FORCE_COMPLEX = 1
 PLANT_NONE, PLANT_HAMILTONIAN, PLANT_GENERATOR = 0, 1, 2
-E_UNSUPPORTED, E_BADARG, E_NODEVICE, E_TIMEOUT = -1001, -1002, -1003, -1004
+E_UNSUPPORTED, E_BADARG, E_NODEVICE, E_TIMEOUT, E_COMM = -1001, -1002, -1003, -1004, -1005
+UNIQUE_ID_BYTES = 128
 
 (F_MODELS, F_X0, F_X_TARG, F_U_TARG, F_Q, F_R, F_QF, F_OP0, F_OPS, F_XS, F_US, F_CODES, F_STEPS_DONE,
  F_QP_SOLVES, F_X_GUESS, F_U_GUESS) = range(16)
@@ -75,6 +76,18 @@ PROTOTYPES = {
     "m4q_session_info": (C.c_int, [_vp, C.POINTER(C.c_int64), _ip, _ip]),
     "m4q_session_qp_stats": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     "m4q_session_path": (C.c_int, [_vp]),
+    "m4q_session_copy_final_state": (C.c_int, [_vp, _vp]),
+    "m4q_session_copy_status": (C.c_int, [_vp, _vp]),
+    "m4q_comm_unique_id": (C.c_int, [_vp]),
+    "m4q_comm_create": (C.c_int, [_i32, _i32, _vp, _i32, C.POINTER(_vp)]),
+    "m4q_comm_destroy": (None, [_vp]),
+    "m4q_comm_gather": (C.c_int, [_vp, _vp, _vp, _vp, C.c_size_t, _i32, _i32]),
+    "m4q_comm_wait": (C.c_int, [_vp, _i32]),
+    "m4q_comm_allreduce_f64": (C.c_int, [_vp, _dp, _i32, _i32]),
+    "m4q_device_alloc": (C.c_int, [C.c_size_t, _i32, C.POINTER(_vp)]),
+    "m4q_device_free": (C.c_int, [_vp]),
+    "m4q_device_read": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "m4q_device_write": (C.c_int, [_vp, _vp, C.c_size_t]),
 }
 
 _lib = None

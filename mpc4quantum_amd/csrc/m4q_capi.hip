@@ -1,6 +1,8 @@
 // m4q_capi.hip - host side of the C ABI declared in include/m4q.h.
 // Owns device memory, streams and events; dispatches to the per-shape kernel objects.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types and prototypes only: librccl.so is loaded with dlopen on first use (a CPU-only import never needs it)
 
 #include <algorithm>
 #include <cmath>
@@ -236,6 +238,8 @@ int m4q_session_create(const m4q_problem* p, int32_t B, int32_t device, m4q_sess
   if (p->horizon < 1 || p->n_steps < 1 || p->target_cols < p->horizon + 1 + (p->n_steps > 1 ? p->n_steps - 2 : 0))
     return fail(M4Q_E_BADARG, "horizon/n_steps/target_cols inconsistent (need target_cols >= n_steps + horizon - 1)");
   if (!(p->sat > 0)) return fail(M4Q_E_BADARG, "sat must be positive (the reference crashes on sat=None, mpc.py Q5)");
+  if (p->qp_flags & ~(M4Q_QP_REF_LQR | M4Q_QP_DU_BAND | M4Q_QP_EXACT_BOX))
+    return fail(M4Q_E_BADARG, "qp_flags has bits outside M4Q_QP_REF_LQR | M4Q_QP_DU_BAND | M4Q_QP_EXACT_BOX (0x%x)", p->qp_flags);
   if ((p->qp_flags & M4Q_QP_EXACT_BOX) && (p->qp_flags & M4Q_QP_REF_LQR))
     return fail(M4Q_E_BADARG, "M4Q_QP_EXACT_BOX cannot be combined with M4Q_QP_REF_LQR");
   {
@@ -446,7 +450,7 @@ int m4q_session_put_state(m4q_session* s, int32_t step, const void* host) {
   HIP_TRY(hipMemcpy2DAsync((char*)s->f[M4Q_F_XS].p + (size_t)step * row, (size_t)(s->prob.n_steps + 1) * row, host, row, row,
                            s->B, hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
-  return 0;
+  return check_watchdog(s);
 }
 
 int m4q_session_get_state(m4q_session* s, int32_t step, void* host) {
@@ -455,7 +459,7 @@ int m4q_session_get_state(m4q_session* s, int32_t step, void* host) {
   HIP_TRY(hipMemcpy2DAsync(host, row, (const char*)s->f[M4Q_F_XS].p + (size_t)step * row, (size_t)(s->prob.n_steps + 1) * row,
                            row, s->B, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
-  return 0;
+  return check_watchdog(s);
 }
 
 void* m4q_session_device_ptr(m4q_session* s, int32_t field) {
@@ -590,7 +594,7 @@ int m4q_session_set_codes(m4q_session* s, const int32_t* codes) {
   if (!s || !codes) return fail(M4Q_E_BADARG, "m4q_session_set_codes: bad argument");
   HIP_TRY(hipMemcpyAsync(s->f[M4Q_F_CODES].p, codes, (size_t)s->B * 4, hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
-  return 0;
+  return check_watchdog(s);
 }
 
 int m4q_session_kernel_ms(m4q_session* s, double* total_ms, int32_t* launches) {
@@ -611,7 +615,7 @@ int m4q_session_kernel_ms(m4q_session* s, double* total_ms, int32_t* launches) {
   s->pending.clear();
   if (total_ms) *total_ms = tot;
   if (launches) *launches = n;
-  return 0;
+  return check_watchdog(s);     // (timings of a launch that left through its watchdog are not handed out as if it had finished)
 }
 
 int m4q_session_qp_stats(m4q_session* s, int64_t* out6) {
@@ -623,7 +627,7 @@ int m4q_session_qp_stats(m4q_session* s, int64_t* out6) {
   if (std::getenv("M4Q_QP_TRACE"))
     fprintf(stderr, "m4q: exact QP: %llu row sweeps in %llu wavefront passes (x4 rows = %llu): lane efficiency %.2f\n", q[2], q[7],
             4 * q[7], q[7] ? (double)q[2] / (4.0 * (double)q[7]) : 0.0);
-  return 0;
+  return check_watchdog(s);
 }
 
 int m4q_session_info(const m4q_session* s, int64_t* hbm_bytes, int32_t* grid, int32_t* lds_bytes) {
@@ -711,6 +715,8 @@ int m4q_quad_program_batch(int32_t B, int32_t dim_x, int32_t dim_u, int32_t T, i
   if (B <= 0 || T <= 0 || !x_init || !X_bm || !U_bm || !Q_ls || !R_ls || !A_ls || !B_ls || !X_opt || !U_opt || !cost)
     return fail(M4Q_E_BADARG, "m4q_quad_program_batch: bad argument");
   if (!(sat > 0)) return fail(M4Q_E_BADARG, "sat must be positive");
+  if (qp_flags & ~(M4Q_QP_REF_LQR | M4Q_QP_DU_BAND | M4Q_QP_EXACT_BOX))
+    return fail(M4Q_E_BADARG, "qp_flags has bits outside M4Q_QP_REF_LQR | M4Q_QP_DU_BAND | M4Q_QP_EXACT_BOX (0x%x)", qp_flags);
   if ((qp_flags & M4Q_QP_EXACT_BOX) && (qp_flags & M4Q_QP_REF_LQR))
     return fail(M4Q_E_BADARG, "M4Q_QP_EXACT_BOX cannot be combined with M4Q_QP_REF_LQR");
   int rc = need_device();
@@ -891,6 +897,192 @@ int m4q_mpc_batch(const m4q_problem* p, int32_t B, const double* models, const d
   if (exit_codes && (rc = m4q_session_download(s, M4Q_F_CODES, exit_codes, s->fbytes[M4Q_F_CODES]))) return rc;
   if (steps_done && (rc = m4q_session_download(s, M4Q_F_STEPS_DONE, steps_done, s->fbytes[M4Q_F_STEPS_DONE]))) return rc;
   if (qp_solves && (rc = m4q_session_download(s, M4Q_F_QP_SOLVES, qp_solves, s->fbytes[M4Q_F_QP_SOLVES]))) return rc;
+  return 0;
+}
+
+int m4q_session_copy_final_state(m4q_session* s, void* dst_dev) {
+  if (!s || !dst_dev) return fail(M4Q_E_BADARG, "m4q_session_copy_final_state: bad argument");
+  const size_t row = (size_t)s->prob.dim_x * 16;
+  HIP_TRY(hipMemcpy2DAsync(dst_dev, row, (const char*)s->f[M4Q_F_XS].p + (size_t)s->prob.n_steps * row,
+                           (size_t)(s->prob.n_steps + 1) * row, row, s->B, hipMemcpyDeviceToDevice, s->stream));
+  return 0;
+}
+
+// the watchdog flag of the launches queued so far, as one int32 in caller-owned device memory (a gather buffer's status word:
+// rank dst learns from the gathered bytes that some rank's launch abandoned itself); enqueued on the session stream
+int m4q_session_copy_status(m4q_session* s, void* dst_dev) {
+  if (!s || !dst_dev) return fail(M4Q_E_BADARG, "m4q_session_copy_status: bad argument");
+  HIP_TRY(hipMemcpyAsync(dst_dev, (const char*)s->queue.p + 4, 4, hipMemcpyDeviceToDevice, s->stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// communicator: RCCL through dlopen (no link-time dependency), its own stream, one event per gather slot
+// ------------------------------------------------------------------------------------------
+namespace {
+struct Rccl {
+  void* h = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGather) Gather = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::string why;
+};
+Rccl* rccl() {
+  static Rccl r;
+  static bool tried = false;
+  if (tried) return &r;
+  tried = true;
+  const char* env = std::getenv("M4Q_RCCL_LIB");
+  const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  for (const char* n : names) {
+    if (!n || !*n) continue;
+    r.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (r.h) break;
+    r.why = dlerror();
+  }
+  if (!r.h) return &r;
+  bool ok = true;
+  auto sym = [&](const char* n) { void* p = dlsym(r.h, n); if (!p) { ok = false; r.why = std::string("missing symbol ") + n; } return p; };
+  r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+  r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+  r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+  r.Gather = (decltype(r.Gather))sym("ncclGather");
+  r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
+  r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+  if (!ok) { dlclose(r.h); r.h = nullptr; }
+  return &r;
+}
+int need_rccl(Rccl** out) {
+  Rccl* r = rccl();
+  if (!r->h) return fail(M4Q_E_COMM, "librccl.so could not be loaded (%s); set M4Q_RCCL_LIB", r->why.c_str());
+  *out = r;
+  return 0;
+}
+#define NCCL_TRY(r, expr)                                                                     \
+  do {                                                                                         \
+    ncclResult_t e_ = (expr);                                                                  \
+    if (e_ != ncclSuccess) return fail(M4Q_E_COMM, "%s: %s", #expr, (r)->GetErrorString(e_)); \
+  } while (0)
+}  // namespace
+
+struct m4q_comm {
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1, device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t slot[8] = {};
+  hipEvent_t dep = nullptr;
+  double* scratch = nullptr;        // 64 doubles in, 64 out (m4q_comm_allreduce_f64)
+};
+
+int m4q_comm_unique_id(void* id128) {
+  static_assert(sizeof(ncclUniqueId) == M4Q_UNIQUE_ID_BYTES, "unique id size");
+  if (!id128) return fail(M4Q_E_BADARG, "m4q_comm_unique_id: null buffer");
+  Rccl* r;
+  int rc = need_rccl(&r);
+  if (rc) return rc;
+  ncclUniqueId id;
+  NCCL_TRY(r, r->GetUniqueId(&id));
+  std::memcpy(id128, &id, sizeof(id));
+  return 0;
+}
+
+int m4q_comm_create(int32_t rank, int32_t world, const void* id128, int32_t device, m4q_comm** out) {
+  if (!out || !id128 || world < 1 || rank < 0 || rank >= world) return fail(M4Q_E_BADARG, "m4q_comm_create: bad argument");
+  int rc = need_device();
+  if (rc) return rc;
+  Rccl* r;
+  if ((rc = need_rccl(&r))) return rc;
+  if (device >= 0) HIP_TRY(hipSetDevice(device));
+  m4q_comm* c = new m4q_comm();
+  c->rank = rank;
+  c->world = world;
+  struct Guard { m4q_comm* c; ~Guard() { if (c) m4q_comm_destroy(c); } } guard{c};
+  HIP_TRY(hipGetDevice(&c->device));
+  HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  for (auto& e : c->slot) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&c->dep, hipEventDisableTiming));
+  HIP_TRY(hipMalloc((void**)&c->scratch, 128 * sizeof(double)));
+  ncclUniqueId id;
+  std::memcpy(&id, id128, sizeof(id));
+  NCCL_TRY(r, r->CommInitRank(&c->comm, world, id, rank));
+  guard.c = nullptr;
+  *out = c;
+  return 0;
+}
+
+void m4q_comm_destroy(m4q_comm* c) {
+  if (!c) return;
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->comm) (void)rccl()->CommDestroy(c->comm);
+  for (auto& e : c->slot) if (e) (void)hipEventDestroy(e);
+  if (c->dep) (void)hipEventDestroy(c->dep);
+  if (c->scratch) (void)hipFree(c->scratch);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int m4q_comm_gather(m4q_comm* c, m4q_session* after, const void* send_dev, void* recv_dev, size_t bytes, int32_t dst, int32_t slot) {
+  if (!c || !send_dev || bytes == 0 || dst < 0 || dst >= c->world || slot < 0 || slot >= 8 || (c->rank == dst && !recv_dev))
+    return fail(M4Q_E_BADARG, "m4q_comm_gather: bad argument");
+  Rccl* r = rccl();
+  if (after) {
+    HIP_TRY(hipEventRecord(c->dep, after->stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->dep, 0));
+  }
+  NCCL_TRY(r, r->Gather(send_dev, recv_dev, bytes, ncclUint8, dst, c->comm, c->stream));
+  HIP_TRY(hipEventRecord(c->slot[slot], c->stream));
+  return 0;
+}
+
+int m4q_comm_wait(m4q_comm* c, int32_t slot) {
+  if (!c || slot >= 8) return fail(M4Q_E_BADARG, "m4q_comm_wait: bad argument");
+  if (slot < 0) HIP_TRY(hipStreamSynchronize(c->stream));
+  else HIP_TRY(hipEventSynchronize(c->slot[slot]));
+  return 0;
+}
+
+int m4q_comm_allreduce_f64(m4q_comm* c, double* inout_host, int32_t n, int32_t op) {
+  if (!c || n < 0 || n > 64 || (n > 0 && !inout_host) || (op != 0 && op != 1)) return fail(M4Q_E_BADARG, "m4q_comm_allreduce_f64: bad argument");
+  Rccl* r = rccl();
+  double one = 0.0;
+  const int cnt = n > 0 ? n : 1;                      // n = 0: a barrier (one dummy element)
+  HIP_TRY(hipMemcpyAsync(c->scratch, n > 0 ? inout_host : &one, cnt * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  NCCL_TRY(r, r->AllReduce(c->scratch, c->scratch + 64, cnt, ncclDouble, op == 0 ? ncclSum : ncclMax, c->comm, c->stream));
+  HIP_TRY(hipMemcpyAsync(n > 0 ? inout_host : &one, c->scratch + 64, cnt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int m4q_device_alloc(size_t bytes, int32_t device, void** out) {
+  if (!out || bytes == 0) return fail(M4Q_E_BADARG, "m4q_device_alloc: bad argument");
+  int rc = need_device();
+  if (rc) return rc;
+  if (device >= 0) HIP_TRY(hipSetDevice(device));
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, bytes));
+  hipError_t e = hipMemset(p, 0, bytes);
+  if (e != hipSuccess) { (void)hipFree(p); return fail(-(int)e, "hipMemset: %s", hipGetErrorString(e)); }
+  *out = p;
+  return 0;
+}
+
+int m4q_device_free(void* dev) {
+  if (dev) HIP_TRY(hipFree(dev));
+  return 0;
+}
+
+int m4q_device_read(void* host, const void* dev, size_t bytes) {
+  if (!host || !dev) return fail(M4Q_E_BADARG, "m4q_device_read: bad argument");
+  HIP_TRY(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int m4q_device_write(void* dev, const void* host, size_t bytes) {
+  if (!host || !dev) return fail(M4Q_E_BADARG, "m4q_device_write: bad argument");
+  HIP_TRY(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice));
   return 0;
 }
 

@@ -80,6 +80,14 @@ class EnsembleSession:
     def bind_output(self, field, device_ptr, nbytes):
         _lib.check(self._L.m4q_session_bind_output(self._h, field, C.c_void_p(device_ptr), nbytes))
 
+    def copy_final_state(self, device_ptr):
+        """xs[:, n_steps, :] -> device memory [B][n] complex, on the session stream (final-state-only gather buffers)."""
+        _lib.check(self._L.m4q_session_copy_final_state(self._h, C.c_void_p(device_ptr)))
+
+    def copy_status(self, device_ptr):
+        """the launch's watchdog flag -> one int32 of device memory, on the session stream (a gather buffer's status word)."""
+        _lib.check(self._L.m4q_session_copy_status(self._h, C.c_void_p(device_ptr)))
+
     def build_models(self, dt, generators, scales=None):
         """Fill the MODELS field on the device: generators [1+m, n, n] (shared) or [B, 1+m, n, n], scales [B, 1+m]."""
         g = np.ascontiguousarray(generators, dtype=np.complex128)

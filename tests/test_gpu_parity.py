@@ -1236,25 +1236,22 @@ def test_exact_qp_unconverged_solves_surface_as_exit_code_2():
     assert code == 2 and xs.shape == (9, k + 1) and (us is None if k == 0 else us.shape == (2, k)) and len(clock.ts_sim) == k
 
 
-def test_mpc_batch_sharded_nccl_single_rank(tmp_path):
-    """The product's multi-GPU function on its RCCL branch (backend "nccl", one rank - all a one-GPU box allows): the session's
-    outputs bound into the torch-owned gather buffer, one dist.gather of device memory, unpack.  Must equal mpc_batch bit for bit,
-    whole state history and final-state-only.  Runs in a child process (the process group and torch's CUDA context stay out of
-    the test process)."""
+def test_mpc_batch_sharded_rccl_single_rank(tmp_path):
+    """The product's multi-GPU function on its RCCL path, through the C ABI alone (m4q_comm_*: ncclCommInitRank, ncclGather on
+    the communicator's stream behind the kernel) with one rank - all a one-GPU box allows: the session's outputs bound into the
+    library-owned gather buffer, one gather of device memory, unpack.  Must equal mpc_batch bit for bit, whole state history and
+    final-state-only.  The child process must never have imported torch."""
     import subprocess
     import sys
-    script = tmp_path / "sharded_nccl.py"
+    script = tmp_path / "sharded_rccl.py"
     script.write_text('''
 import os, sys
 import numpy as np
 sys.path.insert(0, %r)
-os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
-import torch, torch.distributed as dist
+os.environ["RANK"] = "0"; os.environ["WORLD_SIZE"] = "1"; os.environ["LOCAL_RANK"] = "0"; os.environ.setdefault("MASTER_PORT", "29533")
 import mpc4quantum_amd as m4q
 from mpc4quantum_amd import configs
-from mpc4quantum_amd.distributed import mpc_batch_sharded
-torch.cuda.set_device(0)
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from mpc4quantum_amd.distributed import mpc_batch_sharded, RcclComm
 p = configs.build(3, batch=10, horizon=12, n_steps=6)
 def clock(): return m4q.StepClock(p["dt"], p["horizon"], p["n_steps"])
 args = lambda: (p["x0"], p["models"], p["dim_u"], p["order"], p["X_targ"], p["U_targ"], clock(), p["plant_op0"], p["plant_ops"],
@@ -1266,17 +1263,22 @@ for final_only in (False, True):
     assert np.array_equal(got["xs"], xs), ("xs", final_only)
     for k in ("us", "exit_codes", "steps_done", "qp_solves"):
         assert np.array_equal(got[k], ref[k]), (k, final_only)
-dist.destroy_process_group()
-print("sharded nccl ok")
+comm = RcclComm.from_env()
+assert comm.allreduce([1.5, 2.0], "sum").tolist() == [1.5, 2.0] and comm.allreduce([3.0], "max").tolist() == [3.0]
+comm.barrier()
+comm.close()
+assert "torch" not in sys.modules
+print("sharded rccl ok")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "sharded nccl ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+    assert out.returncode == 0 and "sharded rccl ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 
 
 def test_mpc_batch_sharded_two_ranks_on_one_gpu(tmp_path):
-    """Two ranks (backend "gloo", both on the box's one GPU): each runs ITS contiguous block of an 11-member ensemble (6 + 5: the
-    padded-row case) through the HIP kernels, one gather puts the ensemble together on rank 0.  Must equal one mpc_batch over all
-    11 members bit for bit.  (RCCL itself cannot put two ranks on one device; its one-rank case is the test above.)"""
+    """Two ranks (host transport of the test harness, both on the box's one GPU): each runs ITS contiguous block of an 11-member
+    ensemble (6 + 5: the padded-row case) through the HIP kernels, one gather puts the ensemble together on rank 0.  Must equal
+    one mpc_batch over all 11 members bit for bit.  (RCCL itself cannot put two ranks on one device; its one-rank case is the
+    test above.)"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -1285,10 +1287,12 @@ def test_mpc_batch_sharded_two_ranks_on_one_gpu(tmp_path):
 import os, sys
 import numpy as np
 sys.path.insert(0, %r)
+sys.path.insert(0, os.path.join(%r, "tests"))
 import torch.distributed as dist
 import mpc4quantum_amd as m4q
 from mpc4quantum_amd import configs
 from mpc4quantum_amd.distributed import mpc_batch_sharded, shard_bounds
+from gloo_transport import GlooTransport
 rank = int(os.environ["RANK"])
 dist.init_process_group("gloo", rank=rank, world_size=2)
 p = configs.build(3, batch=11, horizon=12, n_steps=6)
@@ -1297,7 +1301,7 @@ args = lambda: (p["x0"], p["models"], p["dim_u"], p["order"], p["X_targ"], p["U_
                 p["Q"], p["R"], p["Qf"], p["sat"], p["du"])
 assert [shard_bounds(11, r, 2) for r in range(2)] == [(0, 6), (6, 11)]
 for final_only in (False, True):
-    got = mpc_batch_sharded(*args(), final_state_only=final_only)
+    got = mpc_batch_sharded(*args(), transport=GlooTransport(), final_state_only=final_only)
     if rank == 0:
         ref = m4q.mpc_batch(*args())
         xs = ref["xs"][:, :, -1:] if final_only else ref["xs"]
@@ -1309,7 +1313,7 @@ for final_only in (False, True):
 dist.barrier()
 dist.destroy_process_group()
 print("rank %%d ok" %% rank)
-''' % root)
+''' % (root, root))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                               text=True) for r in range(2)]
