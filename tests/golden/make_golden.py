@@ -2,7 +2,8 @@
 
 Run once in the build container (where /root/reference exists):
     python tests/golden/make_golden.py
-(`python tests/golden/make_golden.py dmdc` regenerates only dmdc.npz, `... mpc_loop` only mpc_loop.npz.)
+(`python tests/golden/make_golden.py dmdc` regenerates only dmdc.npz, `... mpc_loop` only mpc_loop.npz, `... mpc_long` only
+mpc_loop_long.npz.)
 The reference modules are loaded by file path (the package __init__ needs qutip/cvxpy, which are
 absent); linearize.py, lqr.py, model.py, vectorize.py and - for mpc_loop.npz - mpc.py are executed.
 mpc.py does `from .optimize import quad_program` (cvxpy + OSQP, absent): a stub module of that name forwards
@@ -309,6 +310,156 @@ def loop_cases():
     return cases
 
 
+def install_recorder(ref):
+    """A recording subclass of the reference's WrapModel, bound in mpc.py's namespace: logs the SQP guess handed to
+    get_model_along_traj at every QP solve.  hook["perturb_step"] = k: the linearisation point of the FIRST solve of MPC step k
+    is scaled by (1 + hook["eps"]) on its way into the reference's linearisation (the guess itself is untouched) - used to
+    measure how far the reference's own step outputs move under a perturbation in the last bits."""
+    lin, rmpc = ref["linearize"], ref["mpc"]
+    log, hook = [], {"perturb_step": None, "eps": 1e-15, "dt": 1.0}
+
+    class RecordingWrapModel(lin.WrapModel):
+        def get_model_along_traj(self, xs, us, ts):
+            step = int(round(float(ts[0]) / hook["dt"]))
+            first = not any(int(round(t0 / hook["dt"])) == step for t0, _, _ in log)
+            log.append((float(ts[0]), np.array(xs, dtype=complex), np.array(us, dtype=float)))
+            if hook["perturb_step"] is not None and step == hook["perturb_step"] and first:
+                xs = np.array(xs, dtype=complex) * (1.0 + hook["eps"])
+            return super().get_model_along_traj(xs, us, ts)
+    rmpc.WrapModel = RecordingWrapModel
+    return log, hook
+
+
+def run_loop_case(ref, log, hook, name, c, out, record=True, n_steps=None):
+    """One scenario through the reference's mpc(); everything recorded under "loop_<name>_" in `out` (record=False: return the
+    run's (xs, us, code) only - the perturbed reruns)."""
+    lin, mdl, vec, rmpc = ref["linearize"], ref["model"], ref["vectorize"], ref["mpc"]
+    d, m, dt, T, ns, order = c["d"], c["m"], c["dt"], c["T"], c["n_steps"], c["order"]
+    ns_run = n_steps or ns
+    n = d * d
+    hook["dt"] = dt
+    A_dst = vec.discretize_homogeneous([liou(H) for H in c["H_model"]], dt, order)
+    P = lin.size_of_library(order, m) - 1
+    if c.get("streaming"):
+        model = mdl.OnlineDMDc.from_bootstrap(n, n, n * P, A_dst.copy(), alpha=c["alpha"])
+    else:
+        model = mdl.DMDc(n, n, n * P, A_dst)
+    clock = rmpc.StepClock(dt, T, ns_run)
+    clock.measure_freq = c.get("measure_freq", 1)
+    plant = HeldPlant(c["H_plant"][0], c["H_plant"][1:], c.get("growth", 0.0))
+    cols = ns + T + 1
+    X_targ = np.tile(c["target"].reshape(-1, 1), (1, cols))
+    U_targ = np.zeros((m, cols))
+    Q = np.diag(np.array(c["Qdiag"], dtype=float))
+    R = c["R"] * np.identity(m)
+    x0 = c["x0"] * c.get("x0_scale", 1.0)
+    exit_condition = None
+    if "exit_index" in c:
+        ei, et = c["exit_index"], c["exit_thr"]
+        exit_condition = lambda xn, x, u: abs(xn[ei]) > et          # noqa: E731
+    del log[:]
+    k = "loop_" + name + "_"
+    if record:
+        for key in ("d", "m", "dt", "T", "n_steps", "order", "sat", "du"):
+            out[k + key] = np.array(c[key])
+        out[k + "measure_freq"] = np.array(clock.measure_freq)
+        out[k + "warm_start"] = np.array(bool(c.get("warm_start", True)))
+        out[k + "max_iter"] = np.array(c.get("max_iter", 100))
+        out[k + "growth"] = np.array(c.get("growth", 0.0))
+        out[k + "streaming"], out[k + "alpha"] = np.array(bool(c.get("streaming", False))), np.array(c.get("alpha", 0.0))
+        out[k + "exit_index"], out[k + "exit_thr"] = np.array(c.get("exit_index", -1)), np.array(c.get("exit_thr", 0.0))
+        out[k + "model"], out[k + "x0"] = A_dst, x0
+        out[k + "H_plant"] = np.stack(c["H_plant"])
+        out[k + "X_targ"], out[k + "U_targ"], out[k + "Q"], out[k + "R"] = X_targ, U_targ, Q, R
+    raised = ""
+    try:
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            (xs, us), _, code = rmpc.mpc(x0, m, order, X_targ, U_targ, clock, plant, model, Q, R, Q, sat=c["sat"],
+                                         du=c["du"], max_iter=c.get("max_iter", 100), exit_condition=exit_condition,
+                                         warm_start=c.get("warm_start", True), progress_bar=False,
+                                         streaming=bool(c.get("streaming", False)))
+    except Exception as e:                                       # a NaN state: numpy.linalg.pinv raises inside lqr.py:61
+        raised = type(e).__name__
+        xs, us, code = np.zeros((n, 0)), None, -1
+    if not record:
+        return xs, us, code
+    out[k + "raised"] = np.array(raised)
+    out[k + "model_final"] = np.array(model.A)
+    out[k + "xs"] = xs
+    out[k + "us"] = us if us is not None else np.zeros((m, 0))
+    out[k + "us_is_none"] = np.array(us is None)
+    out[k + "exit_code"] = np.array(code)
+    out[k + "ts_sim"] = np.asarray(clock.ts_sim)
+    out[k + "solve_step"] = np.array([int(round(t0 / dt)) for t0, _, _ in log], dtype=np.int32)
+    out[k + "solve_Xg"] = np.stack([xg for _, xg, _ in log]) if log else np.zeros((0, n, T + 1), dtype=complex)
+    out[k + "solve_Ug"] = np.stack([ug for _, _, ug in log]) if log else np.zeros((0, m, T))
+    print("%-24s exit_code %2d raised %-12s xs %s QP solves %d" % (name, code, raised or "-", xs.shape, len(log)))
+    return xs, us, code
+
+
+def long_cases():
+    """BASELINE horizons: config 3 (T = 40, 20 steps) members 0 and 1 of its 65,536-member model ensemble, config 5 (T = 80)
+    member 0 of its 2^20-member ensemble, 10 steps.  Parameters exactly as mpc4quantum_amd/configs.py builds them from
+    tests/test_mpc4quantum.py:504-564 and tests/util_qubits.py:92-111: per-member model anharmonicity alpha0 (1 + 0.05 xi) and
+    drive scale 1 + 0.02 zeta, nominal plant."""
+    def proj(d, i):
+        P = np.zeros((d, d), dtype=complex)
+        P[i, i] = 1
+        return P
+    dt = 0.25
+    alpha0 = -2 * np.pi * 0.1 / dt
+    a = np.diag(np.sqrt(np.arange(1, 3)), 1).astype(complex)
+    HX, HY = 0.5 * (a.conj().T + a), 0.5j * (a.conj().T - a)
+    sat = 2 * np.pi * 0.25
+    rho0 = proj(3, 0)
+    r = rx(1e-4)
+    rho0[:2, :2] = r.conj().T @ rho0[:2, :2] @ r
+    cases = {}
+    for tag, seed, total, T, ns, members in (("T40", 3, 65536, 40, 20, (0, 1)), ("T80", 5, 2 ** 20, 80, 10, (0,))):
+        rng = np.random.default_rng(seed)
+        xi = rng.standard_normal(total)
+        zeta = rng.standard_normal(total)
+        for b in members:
+            s0, s1 = 1 + 0.05 * xi[b], 1 + 0.02 * zeta[b]
+            cases["transmon_o1_%s_m%d" % (tag, b)] = dict(
+                d=3, m=2, dt=dt, order=1, T=T, n_steps=ns, H_model=[s0 * alpha0 * proj(3, 2), s1 * HX, s1 * HY],
+                H_plant=[alpha0 * proj(3, 2), HX, HY], x0=rho0.reshape(-1), target=proj(3, 1).reshape(-1), sat=sat, du=0.5 * sat,
+                Qdiag=[1.0, 0, 0, 0, 1.0, 0, 0, 0, 0], R=1e-3 / sat ** 2)
+    return cases
+
+
+def golden_mpc_long():
+    """(7) the reference's mpc() at the BASELINE horizons (mpc_loop.npz stops at T = 12), same harness as (6), plus the
+    reference's OWN sensitivity: for every MPC step k the run is repeated with the linearisation point of step k's first QP solve
+    scaled by 1 + 1e-15; sens_us[k] = max |us[k] - us_perturbed[k]|, sens_xs[k] likewise for xs[k+1].  A step whose outputs the
+    reference itself does not determine beyond sens cannot be held tighter by anything compared with it."""
+    ref = load_reference_mpc()
+    log, hook = install_recorder(ref)
+    out = {}
+    names = []
+    for name, c in long_cases().items():
+        names.append(name)
+        xs, us, code = run_loop_case(ref, log, hook, name, c, out)
+        ns = c["n_steps"]
+        sens_u, sens_x = np.zeros(ns), np.zeros(ns)
+        for k in range(ns):
+            hook["perturb_step"] = k
+            xs_p, us_p, code_p = run_loop_case(ref, log, hook, name, c, out, record=False, n_steps=k + 1)
+            hook["perturb_step"] = None
+            assert code_p == 0 and us_p.shape[1] == k + 1
+            assert k == 0 or np.array_equal(us_p[:, :k], us[:, :k])           # identical up to the perturbed step
+            sens_u[k] = np.abs(us_p[:, k] - us[:, k]).max()
+            sens_x[k] = np.abs(xs_p[:, k + 1] - xs[:, k + 1]).max()
+        out["loop_" + name + "_sens_us"], out["loop_" + name + "_sens_xs"] = sens_u, sens_x
+        print("   reference's own sensitivity to 1e-15 in the guess: max over steps  us %.2e  xs %.2e" % (sens_u.max(), sens_x.max()))
+        print("   per step us:", " ".join("%.1e" % v for v in sens_u))
+    out["loop_names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "mpc_loop_long.npz"), **out)
+    print("wrote mpc_loop_long.npz")
+
+
 def golden_mpc_loop():
     """(6) the reference's closed-loop driver, mpc.py:101-125 (iqp_line_search) and :128-304 (mpc), run as described in the
     module docstring.  Recorded per scenario: every input, the returned xs / us / exit_code, clock.ts_sim, and - through a
@@ -351,73 +502,11 @@ def golden_mpc_loop():
     out["clock_string"] = np.array(ck.to_string())
 
     # ---- mpc()
-    log = []
-
-    class RecordingWrapModel(lin.WrapModel):
-        def get_model_along_traj(self, xs, us, ts):
-            log.append((float(ts[0]), np.array(xs, dtype=complex), np.array(us, dtype=float)))
-            return super().get_model_along_traj(xs, us, ts)
-    rmpc.WrapModel = RecordingWrapModel
+    log, hook = install_recorder(ref)
     names = []
     for name, c in loop_cases().items():
-        d, m, dt, T, ns, order = c["d"], c["m"], c["dt"], c["T"], c["n_steps"], c["order"]
-        n = d * d
-        A_dst = vec.discretize_homogeneous([liou(H) for H in c["H_model"]], dt, order)
-        P = lin.size_of_library(order, m) - 1
-        if c.get("streaming"):
-            model = mdl.OnlineDMDc.from_bootstrap(n, n, n * P, A_dst.copy(), alpha=c["alpha"])
-        else:
-            model = mdl.DMDc(n, n, n * P, A_dst)
-        clock = rmpc.StepClock(dt, T, ns)
-        clock.measure_freq = c.get("measure_freq", 1)
-        plant = HeldPlant(c["H_plant"][0], c["H_plant"][1:], c.get("growth", 0.0))
-        cols = ns + T + 1
-        X_targ = np.tile(c["target"].reshape(-1, 1), (1, cols))
-        U_targ = np.zeros((m, cols))
-        Q = np.diag(np.array(c["Qdiag"], dtype=float))
-        R = c["R"] * np.identity(m)
-        x0 = c["x0"] * c.get("x0_scale", 1.0)
-        exit_condition = None
-        if "exit_index" in c:
-            ei, et = c["exit_index"], c["exit_thr"]
-            exit_condition = lambda xn, x, u: abs(xn[ei]) > et          # noqa: E731
-        del log[:]
-        k = "loop_" + name + "_"
         names.append(name)
-        for key in ("d", "m", "dt", "T", "n_steps", "order", "sat", "du"):
-            out[k + key] = np.array(c[key])
-        out[k + "measure_freq"] = np.array(clock.measure_freq)
-        out[k + "warm_start"] = np.array(bool(c.get("warm_start", True)))
-        out[k + "max_iter"] = np.array(c.get("max_iter", 100))
-        out[k + "growth"] = np.array(c.get("growth", 0.0))
-        out[k + "streaming"], out[k + "alpha"] = np.array(bool(c.get("streaming", False))), np.array(c.get("alpha", 0.0))
-        out[k + "exit_index"], out[k + "exit_thr"] = np.array(c.get("exit_index", -1)), np.array(c.get("exit_thr", 0.0))
-        out[k + "model"], out[k + "x0"] = A_dst, x0
-        out[k + "H_plant"] = np.stack(c["H_plant"])
-        out[k + "X_targ"], out[k + "U_targ"], out[k + "Q"], out[k + "R"] = X_targ, U_targ, Q, R
-        raised = ""
-        try:
-            import warnings
-            with warnings.catch_warnings():
-                warnings.simplefilter("ignore")
-                (xs, us), _, code = rmpc.mpc(x0, m, order, X_targ, U_targ, clock, plant, model, Q, R, Q, sat=c["sat"],
-                                             du=c["du"], max_iter=c.get("max_iter", 100), exit_condition=exit_condition,
-                                             warm_start=c.get("warm_start", True), progress_bar=False,
-                                             streaming=bool(c.get("streaming", False)))
-        except Exception as e:                                       # a NaN state: numpy.linalg.pinv raises inside lqr.py:61
-            raised = type(e).__name__
-            xs, us, code = np.zeros((n, 0)), None, -1
-        out[k + "raised"] = np.array(raised)
-        out[k + "model_final"] = np.array(model.A)
-        out[k + "xs"] = xs
-        out[k + "us"] = us if us is not None else np.zeros((m, 0))
-        out[k + "us_is_none"] = np.array(us is None)
-        out[k + "exit_code"] = np.array(code)
-        out[k + "ts_sim"] = np.asarray(clock.ts_sim)
-        out[k + "solve_step"] = np.array([int(round(t0 / dt)) for t0, _, _ in log], dtype=np.int32)
-        out[k + "solve_Xg"] = np.stack([xg for _, xg, _ in log]) if log else np.zeros((0, n, T + 1), dtype=complex)
-        out[k + "solve_Ug"] = np.stack([ug for _, _, ug in log]) if log else np.zeros((0, m, T))
-        print("%-24s exit_code %2d raised %-12s xs %s QP solves %d" % (name, code, raised or "-", xs.shape, len(log)))
+        run_loop_case(ref, log, hook, name, c, out)
     out["loop_names"] = np.array(names)
     np.savez_compressed(os.path.join(OUT, "mpc_loop.npz"), **out)
     print("wrote mpc_loop.npz")
@@ -428,7 +517,10 @@ if __name__ == "__main__":
         golden_dmdc()
     elif sys.argv[1:] == ["mpc_loop"]:
         golden_mpc_loop()
+    elif sys.argv[1:] == ["mpc_long"]:
+        golden_mpc_long()
     else:
         main()
         golden_dmdc()
         golden_mpc_loop()
+        golden_mpc_long()

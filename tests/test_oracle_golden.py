@@ -241,14 +241,28 @@ def test_shift_guess_and_clock_vs_reference_mpc_py(golden):
     assert np.array_equal(ck.ts_sim, g["clock_ts_sim6"])
 
 
-@pytest.mark.parametrize("name", LOOPS_OK)
+# tests/golden/mpc_loop_long.npz: the same harness at the BASELINE horizons - config 3 (T = 40, 20 steps, members 0 and 1 of the
+# model ensemble) and config 5 (T = 80, 10 steps) - with the reference's OWN sensitivity per step (rerun with the linearisation
+# point of the step's first QP solve scaled by 1 + 1e-15): sens_us / sens_xs.
+LOOPS_LONG = ["transmon_o1_T40_m0", "transmon_o1_T40_m1", "transmon_o1_T80_m0"]
+
+
+def _which(name):
+    return "mpc_loop_long" if name in LOOPS_LONG else "mpc_loop"
+
+
+@pytest.mark.parametrize("name", LOOPS_OK + LOOPS_LONG)
 def test_mpc_loop_teacher_forced_vs_reference_mpc_py(golden, name):
     """Every MPC step of the reference's run, restarted from the REFERENCE's state (xs, us, SQP guess at the first QP
     solve of the step): the oracle must make the same number of QP solves with the same SQP iterates and produce the same
-    us[k], xs[k+1].  Step by step the comparison is not polluted by the conditioning of the free-running loop."""
-    c = loop_case(golden("mpc_loop"), name)
+    us[k], xs[k+1].  Step by step the comparison is not polluted by the conditioning of the free-running loop.
+    At the BASELINE horizons the bound of a step is widened by ten times what the REFERENCE itself moves under a 1e-15
+    perturbation of that step's linearisation point (recorded in the fixture; at most 3e-13)."""
+    c = loop_case(golden(_which(name)), name)
     steps, Xg, Ug = c["solve_step"], c["solve_Xg"], c["solve_Ug"]
     assert int(c["exit_code"]) == 0
+    su = c.get("sens_us", np.zeros(c["n_steps"]))
+    sx = c.get("sens_xs", np.zeros(c["n_steps"]))
     for k in range(c["n_steps"]):
         idx = np.nonzero(steps == k)[0]
         st = dict(step=k, xs=c["xs"], us=c["us"], X_guess=Xg[idx[0]], U_guess=Ug[idx[0]])
@@ -258,8 +272,8 @@ def test_mpc_loop_teacher_forced_vs_reference_mpc_py(golden, name):
         for (s_k, X, U), i in zip(tr, idx):
             assert s_k == k
             assert np.abs(X - Xg[i]).max() <= 1e-10 and np.abs(U - Ug[i]).max() <= 1e-10, (k, i)
-        assert np.abs(us[:, k] - c["us"][:, k]).max() <= 1e-11, (k, np.abs(us[:, k] - c["us"][:, k]).max())
-        assert np.abs(xs[:, k + 1] - c["xs"][:, k + 1]).max() <= 1e-11, k
+        assert np.abs(us[:, k] - c["us"][:, k]).max() <= 1e-11 + 10 * su[k], (k, np.abs(us[:, k] - c["us"][:, k]).max())
+        assert np.abs(xs[:, k + 1] - c["xs"][:, k + 1]).max() <= 1e-11 + 10 * sx[k], k
 
 
 @pytest.mark.parametrize("name", LOOPS_OK)
