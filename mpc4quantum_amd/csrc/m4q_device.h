@@ -58,16 +58,50 @@ __device__ __forceinline__ cplx csel(bool c, cplx a, cplx b) { return mk(c ? a.r
 // Every global array is reached as  base + zext(off)  so loads/stores use the saddr form and a
 // pointer costs one VGPR, not a 64-bit pair per array kept live across the horizon loops.
 // Per-lane offsets only ever span the four instances of one quad, far below 4 GiB.
+// The base is typed as a GLOBAL-address-space pointer (m4q_args.h): kernel arguments are read out of the kernarg
+// segment where they are used, and a pointer that comes out of memory would otherwise be a flat one.
+#if !defined(M4Q_GLOBAL) || !defined(M4Q_KERNEL_TU)
+#undef M4Q_GLOBAL
+#define M4Q_GLOBAL __attribute__((address_space(1)))
+#endif
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+// loads / stores through global pointers (cplx travels as a 16-byte vector: one dwordx4 access)
+template <class T> struct GMem;
+template <> struct GMem<double> {
+  static __device__ __forceinline__ double ld(const M4Q_GLOBAL char* p) { return *reinterpret_cast<const M4Q_GLOBAL double*>(p); }
+  static __device__ __forceinline__ void st(M4Q_GLOBAL char* p, double v) { *reinterpret_cast<M4Q_GLOBAL double*>(p) = v; }
+};
+template <> struct GMem<int> {
+  static __device__ __forceinline__ int ld(const M4Q_GLOBAL char* p) { return *reinterpret_cast<const M4Q_GLOBAL int*>(p); }
+  static __device__ __forceinline__ void st(M4Q_GLOBAL char* p, int v) { *reinterpret_cast<M4Q_GLOBAL int*>(p) = v; }
+};
+template <> struct GMem<cplx> {
+  static __device__ __forceinline__ cplx ld(const M4Q_GLOBAL char* p) {
+    const d2_t v = *reinterpret_cast<const M4Q_GLOBAL d2_t*>(p);
+    return mk(v.x, v.y);
+  }
+  static __device__ __forceinline__ void st(M4Q_GLOBAL char* p, cplx c) {
+    d2_t v; v.x = c.re; v.y = c.im;
+    *reinterpret_cast<M4Q_GLOBAL d2_t*>(p) = v;
+  }
+};
+// element idx of a global array (wave-uniform or per-lane pointer alike)
+template <class T>
+__device__ __forceinline__ T gld(const M4Q_GLOBAL T* p, long idx) { return GMem<T>::ld(reinterpret_cast<const M4Q_GLOBAL char*>(p + idx)); }
+template <class T>
+__device__ __forceinline__ void gst(M4Q_GLOBAL T* p, long idx, T v) { GMem<T>::st(reinterpret_cast<M4Q_GLOBAL char*>(p + idx), v); }
+
 struct GView {
-  char* base;      // must be wave-uniform
-  unsigned off;    // per-lane, bytes
+  M4Q_GLOBAL char* base;   // must be wave-uniform
+  unsigned off;            // per-lane, bytes
   template <class T>
   __device__ __forceinline__ T ld(unsigned idx) const {
-    return *reinterpret_cast<const T*>(base + (size_t)(off + idx * (unsigned)sizeof(T)));
+    return GMem<T>::ld(base + (size_t)(off + idx * (unsigned)sizeof(T)));
   }
   template <class T>
   __device__ __forceinline__ void st(unsigned idx, T v) const {
-    *reinterpret_cast<T*>(base + (size_t)(off + idx * (unsigned)sizeof(T))) = v;
+    GMem<T>::st(base + (size_t)(off + idx * (unsigned)sizeof(T)), v);
   }
   // same array, base advanced by a uniform number of elements
   template <class T>
@@ -81,9 +115,9 @@ struct GView {
   }
 };
 template <class T>
-__device__ __forceinline__ GView gview(const T* p, long uniform_elems, unsigned lane_elems) {
+__device__ __forceinline__ GView gview(const M4Q_GLOBAL T* p, long uniform_elems, unsigned lane_elems) {
   GView v;
-  v.base = reinterpret_cast<char*>(const_cast<T*>(p)) + uniform_elems * (long)sizeof(T);
+  v.base = (M4Q_GLOBAL char*)p + uniform_elems * (long)sizeof(T);
   v.off = lane_elems * (unsigned)sizeof(T);
   return v;
 }

@@ -3,6 +3,7 @@
 // One wavefront per workgroup; each of its four DPP rows runs one MPC instance (m4q_device.h).
 // The persistent kernel strides over instance quads, so a fixed pool of per-row workspace stays
 // cache resident whatever the ensemble size.
+#define M4Q_KERNEL_TU 1
 #include "m4q_args.h"
 #include "m4q_mpc.h"
 
@@ -45,18 +46,16 @@ extern __shared__ __align__(16) unsigned char m4q_lds_raw[];
 
 // copy one instance's model (DMDc.A layout, n x n(1+P) row-major) into its LDS block [1+P][n][PITCH]
 template <class S>
-__device__ __forceinline__ void stage_model(S* dst, const S* src, int jj) {
+__device__ __forceinline__ void stage_model(S* dst, const M4Q_GLOBAL S* src, int jj) {
   constexpr int W = NX * (1 + NP);
-#ifndef M4Q_STAGE_UNROLL
-#define M4Q_STAGE_UNROLL 1
-#endif
-#pragma unroll M4Q_STAGE_UNROLL
+  // (not unrolled: unrolling this loop costs registers and time, profiles/r02_ab_experiments.txt)
+#pragma unroll 1
   for (int e = jj; e < NX * W; e += 16) {
     const int i = e / W;
     const int pk = e - i * W;
     const int p = pk / NX;
     const int k = pk - p * NX;
-    dst[ModelPitch<NX>::at(p, i, k)] = src[e];
+    dst[ModelPitch<NX>::at(p, i, k)] = gld(src, e);
   }
 }
 
@@ -95,138 +94,171 @@ struct LaneGeo {
 // ---------------------------------------------------------------------------------------------
 constexpr int COST_ELEMS = 2 * NX * NX + NU * NU;         // Q, Qf, R staged in LDS once per workgroup
 constexpr int WLS_DOUBLES = 4 * NX + 2 * NU;               // diagonal line-search weights, staged after them
+constexpr int STASH_INTS = 12;                             // per-row words of RowStash
+constexpr int STASH_BYTES = 8 /* watchdog deadline */ + ROWS * STASH_INTS * 4 + 64 * 16 /* x_meas, one S per lane */;
 
 template <class S>
 constexpr size_t mpc_lds_layout_bytes() {
   return sizeof(S) * (size_t)(ROWS * MODEL_ELEMS + COST_ELEMS) + sizeof(cplx) * (size_t)(ROWS * SCRATCH_ELEMS) +
-         sizeof(double) * (size_t)(WLS_DOUBLES + 2);
+         sizeof(double) * (size_t)WLS_DOUBLES + (size_t)STASH_BYTES;
 }
 
 __device__ __forceinline__ int row_bcast_int(int v) { return __shfl(v, 0, 16); }
 
+// Kernel arguments are read out of the kernarg segment WHERE THEY ARE USED.  Taken as a by-value parameter the 46 fields of
+// MpcArgs are loaded at kernel entry, stay live for the whole persistent loop and - the kernel has 106 scalar registers -
+// end up in VGPR lanes (v_writelane / v_readlane: 161 "spilled SGPRs" in the round-2 build of the headline kernel, 445
+// v_readlane per pass of the main loop).  kargs() returns the segment pointer through an opaque asm, once per phase of the
+// loop: the compiler can neither hoist the loads of one phase to the kernel entry nor keep their results alive into the next.
+typedef const __attribute__((address_space(4))) MpcArgs KArgs;
+__device__ __forceinline__ KArgs* kargs() {
+  KArgs* p = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();      // explicit arguments start at offset 0
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
+// Per-row state that only the bookkeeping phases of the loop need, parked in LDS while the two sweeps run (they take the
+// whole register file; left to the compiler these values went to scratch: 178 spilled VGPRs in the round-2 headline kernel).
+// Row-uniform words are written by the row's lane 0 and read back as an LDS broadcast; volatile, so that the values are
+// really re-read after the sweeps instead of being carried in registers across them.
+#define M4Q_LDS __attribute__((address_space(3)))
+template <class S>
+struct RowStash {
+  volatile M4Q_LDS int* w;          // [ROWS][STASH_INTS]
+  volatile M4Q_LDS double* xm;      // [64][2]
+  __device__ __forceinline__ void put_int(int g, int jj, int slot, int v) const { if (jj == 0) w[g * STASH_INTS + slot] = v; }
+  __device__ __forceinline__ int get_int(int g, int slot) const { return w[g * STASH_INTS + slot]; }
+  __device__ __forceinline__ void put_x(double v) const { xm[2 * threadIdx.x] = v; }
+  __device__ __forceinline__ void put_x(cplx v) const { xm[2 * threadIdx.x] = v.re; xm[2 * threadIdx.x + 1] = v.im; }
+  __device__ __forceinline__ void get_x(double& v) const { v = xm[2 * threadIdx.x]; }
+  __device__ __forceinline__ void get_x(cplx& v) const { v.re = xm[2 * threadIdx.x]; v.im = xm[2 * threadIdx.x + 1]; }
+};
+
 template <class S, int PLANT, bool EXACT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>::value, 8))) void mpc_kernel(MpcArgs a) {
-  // LDS: [4 x scratch (complex)] [4 x model (S)] [Q Qf R (S)] [line-search weights]
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>::value, 8))) void mpc_kernel(MpcArgs) {
+  // LDS: [4 x scratch (complex)] [4 x model (S)] [Q Qf R (S)] [line-search weights] [watchdog deadline, row stash]
   cplx* scratch = reinterpret_cast<cplx*>(m4q_lds_raw);
   S* lds = reinterpret_cast<S*>(scratch + ROWS * SCRATCH_ELEMS);
   const LaneGeo L;
   const int g = L.g, jj = L.jj, j = L.j;
   const bool lane_ok = L.lane_ok;
-  const int T = a.T;
   S* mdl = lds + g * MODEL_ELEMS;
   scratch += g * SCRATCH_ELEMS;
   S* ldsQ = lds + ROWS * MODEL_ELEMS;
-  {
-    const S* gQ = static_cast<const S*>(a.Q);
-    const S* gQf = static_cast<const S*>(a.Qf);
-    const S* gR = static_cast<const S*>(a.R);
-    for (int e = threadIdx.x; e < COST_ELEMS; e += 64)
-      ldsQ[e] = e < NX * NX ? gQ[e] : (e < 2 * NX * NX ? gQf[e - NX * NX] : gR[e - 2 * NX * NX]);
-  }
   double* ldsW = reinterpret_cast<double*>(ldsQ + COST_ELEMS);
-  const bool ls_diag = a.Wls != nullptr;
-  if (ls_diag) {
-    for (int e = threadIdx.x; e < WLS_DOUBLES; e += 64) ldsW[e] = a.Wls[e];
+  volatile M4Q_LDS unsigned long long* wd_slot = (volatile M4Q_LDS unsigned long long*)(ldsW + WLS_DOUBLES);
+  RowStash<S> stash;
+  stash.w = (volatile M4Q_LDS int*)(ldsW + WLS_DOUBLES + 1);
+  stash.xm = (volatile M4Q_LDS double*)(stash.w + ROWS * STASH_INTS);
+  int T0, flags;
+  bool ls_diag, two_phase;
+  {
+    KArgs* a = kargs();
+    T0 = a->T;
+    flags = a->flags;
+    const M4Q_GLOBAL S* gQ = (const M4Q_GLOBAL S*)a->Q;
+    const M4Q_GLOBAL S* gQf = (const M4Q_GLOBAL S*)a->Qf;
+    const M4Q_GLOBAL S* gR = (const M4Q_GLOBAL S*)a->R;
+    for (int e = threadIdx.x; e < COST_ELEMS; e += 64)
+      ldsQ[e] = e < NX * NX ? gld(gQ, e) : (e < 2 * NX * NX ? gld(gQf, e - NX * NX) : gld(gR, e - 2 * NX * NX));
+    ls_diag = a->Wls != nullptr;
+    if (ls_diag) {
+      for (int e = threadIdx.x; e < WLS_DOUBLES; e += 64) ldsW[e] = gld(a->Wls, e);
+    }
+    // cut the run in two work items per instance when the launch covers both regimes
+    two_phase = a->step_begin < 2 && a->step_end > 2;
+    // Watchdog.  The loop below ends when the queue is empty and every row has finished, and a tail item waits for a flag another
+    // workgroup sets: exits that depend on data.  A persistent kernel whose wavefronts never finish takes the GPU (and on this pool
+    // the host's other GPUs) down with it, so every wavefront also leaves once the constant 100 MHz clock has advanced
+    // deadline_ticks since it started; the host finds queue[1] set and fails the launch loudly (M4Q_E_TIMEOUT).  Every loop of
+    // the kernel without a data-independent trip bound passes through this check: the main loop below (one pass = at most one
+    // QP solve or one active-set iteration per row; the head-flag poll is a pass of it that only sleeps), nothing else - the
+    // horizon loops run T trips, the plant's squaring loop at most 60, the staging loops over fixed sizes.
+    if (threadIdx.x == 0) *wd_slot = __builtin_amdgcn_s_memrealtime() + a->deadline_ticks;
   }
   CostRef<S> cost;
   cost.Q = ldsQ; cost.Qf = ldsQ + NX * NX; cost.q_stride = 0; cost.R = ldsQ + 2 * NX * NX; cost.r_stride = 0;
   // workspace of this resident row: wave-uniform base per workgroup, lane part = row within the wave
-  const unsigned sX = (unsigned)(T + 1) * NX, sU = (unsigned)T * NU, sG = (unsigned)T * (NX + 1) * NU;
+  const unsigned sX = (unsigned)(T0 + 1) * NX, sU = (unsigned)T0 * NU, sG = (unsigned)T0 * (NX + 1) * NU;
   // Lanes NX..15 of a row own no column (7 of 16 at d = 3, 12 of 16 at d = 2).  Left enabled they run the sweeps on a copy of
   // column NX-1's data: harmless for the results, but the fp64 pipe spends power on them, and the clock this chip holds under an
   // fp64-dense load follows the power.  EXEC is therefore off for them during the two sweeps (every DPP source is a lane < NX;
   // results bit-identical): the complex path runs at 2.30 GHz instead of 2.04 (133.3 -> 117.6 ms, config 3), the real path at 2.29
   // instead of 2.18 (51.2 -> 50.4 ms; config 5's share 171.2 -> 166.3 ms).  profiles/r02_ab_experiments.txt, r02_clock_ramp.txt.
   constexpr bool MASK_IDLE = M4Q_MASK_IDLE && NX < 16 && !EXACT;
-#ifndef M4Q_WD_LDS
-#define M4Q_WD_LDS 1
-#endif
-#ifndef M4Q_EXP
-#define M4Q_EXP 0
-#endif
-  // (timing-only ablations, results wrong: M4Q_EXP & 64 - every workgroup uses workgroup 0's gain workspace, & 128 - and its
-  //  trajectory workspace: what the launch would take if those bytes came from the L2 instead of the Infinity Cache / HBM)
-  const long wsb = (M4Q_EXP & 128) ? 0 : (long)blockIdx.x, wsg = (M4Q_EXP & 64) ? 0 : (long)blockIdx.x;
-  const GView Xg = gview(static_cast<S*>(a.ws_Xg), wsb * ROWS * sX, g * sX);
-  const GView Ug = gview(a.ws_Ug, wsb * ROWS * sU, g * sU);
-  // (Xo, Uo) live in the same allocations right behind all the (Xg, Ug): same wave-uniform base, so a row can
-  // direct its rollout output to either by its lane offset alone
-  const GView Xo = gview(static_cast<S*>(a.ws_Xg), wsb * ROWS * sX, g * sX + gridDim.x * ROWS * sX);
-  const GView Uo = gview(a.ws_Ug, wsb * ROWS * sU, g * sU + gridDim.x * ROWS * sU);
-  const GView gains = gview(static_cast<S*>(a.ws_gains), wsg * ROWS * sG, g * sG);
-  // EXACT (M4Q_QP_EXACT_BOX): third trajectory pair, working set and Newton point of the projected-Newton solver,
-  // again behind the others in the same allocations
-  const GView Xalt = gview(static_cast<S*>(a.ws_Xg), wsb * ROWS * sX, g * sX + 2 * gridDim.x * ROWS * sX);
-  const GView Ualt = gview(a.ws_Ug, wsb * ROWS * sU, g * sU + 2 * gridDim.x * ROWS * sU);
-  const GView pin_stat = gview(a.ws_Ug, wsb * ROWS * sU, g * sU + 3 * gridDim.x * ROWS * sU);
-  FusedProv<S, NX, NU, ORDER> prov;
-  prov.mdl = mdl; prov.Xg = Xg; prov.Ug = Ug; prov.j = j;
-  const long sXs = (long)(a.n_steps + 1) * NX, sUs = (long)a.n_steps * NU;
-  const bool band = (a.flags & QP_DU_BAND) != 0;
-  const S* x_targ = static_cast<const S*>(a.x_targ);
-
-  // cut the run in two work items per instance when the launch covers both regimes
-  const bool two_phase = a.step_begin < 2 && a.step_end > 2;
-  const int n_items = two_phase ? 2 * a.B : a.B;
+  GView Xg, Ug, Xo, Uo, gains, Xalt, Ualt, pin_stat;
+  {
+    KArgs* a = kargs();
+    const long wsb = (long)blockIdx.x;
+    M4Q_GLOBAL S* wX = (M4Q_GLOBAL S*)a->ws_Xg;
+    Xg = gview(wX, wsb * ROWS * sX, g * sX);
+    Ug = gview(a->ws_Ug, wsb * ROWS * sU, g * sU);
+    // (Xo, Uo) live in the same allocations right behind all the (Xg, Ug): same wave-uniform base, so a row can
+    // direct its rollout output to either by its lane offset alone
+    Xo = gview(wX, wsb * ROWS * sX, g * sX + gridDim.x * ROWS * sX);
+    Uo = gview(a->ws_Ug, wsb * ROWS * sU, g * sU + gridDim.x * ROWS * sU);
+    gains = gview((M4Q_GLOBAL S*)a->ws_gains, wsb * ROWS * sG, g * sG);
+    // EXACT (M4Q_QP_EXACT_BOX): third trajectory pair, working set and Newton point of the projected-Newton solver,
+    // again behind the others in the same allocations
+    Xalt = gview(wX, wsb * ROWS * sX, g * sX + 2 * gridDim.x * ROWS * sX);
+    Ualt = gview(a->ws_Ug, wsb * ROWS * sU, g * sU + 2 * gridDim.x * ROWS * sU);
+    pin_stat = gview(a->ws_Ug, wsb * ROWS * sU, g * sU + 3 * gridDim.x * ROWS * sU);
+  }
+  const bool band = (flags & QP_DU_BAND) != 0;
 
   // per-row state (uniform inside a row)
   long b = 0;
   bool active = false, need_new = true, pending = false;
   int step = 0, iter = 0, code = 0, done_steps = 0;
-  int row_begin = a.step_begin, row_end = a.step_end;
+  int row_begin = 0, row_end = 0;
   S x_cur = zero_of<S>();
   S x_meas = zero_of<S>();     // last MEASURED state (xs[k * measure_freq]); equals x_cur when measure_freq == 1
-  const int mf = a.measure_freq;
   double uprev[NU];
 #pragma unroll
   for (int k = 0; k < NU; ++k) uprev[k] = 0.0;
   BoxQpRow qp;                 // EXACT: the box-QP solve this row has in progress (spans iterations of the loop below)
   int qp_passes = 0;           // passes of this wavefront through the solver iteration (statistics)
-  GView xt = gview(x_targ, 0, 0), ut = gview(a.u_targ, 0, 0), op0 = gview(a.op0, 0, 0), ops = gview(a.ops, 0, 0);
+  unsigned xt_off = 0, ut_off = 0, op0_off = 0, ops_off = 0;      // this row's member inside the per-member arrays (bytes)
   wave_sync();
 
-  // Watchdog.  The loop below ends when the queue is empty and every row has finished, and a tail item waits for a flag another
-  // workgroup sets: exits that depend on data.  A persistent kernel whose wavefronts never finish takes the GPU (and on this pool
-  // the host's other GPUs) down with it, so every wavefront also leaves once the constant 100 MHz clock has advanced
-  // a.deadline_ticks since it started; the host finds queue[1] set and fails the launch loudly (M4Q_E_TIMEOUT).
-#if M4Q_WD_LDS == 1
-  // (the deadline lives in LDS, not in two more scalar registers of a kernel that already spills 150 of them)
-  volatile unsigned long long* wd_slot = reinterpret_cast<volatile unsigned long long*>(ldsW + WLS_DOUBLES);
-  if (threadIdx.x == 0) *wd_slot = __builtin_amdgcn_s_memrealtime() + a.deadline_ticks;
-  wave_sync();
-#elif M4Q_WD_LDS == 0
-  const unsigned long long wd_start = __builtin_amdgcn_s_memrealtime();
-#endif
   while (true) {
-#if M4Q_WD_LDS == 1
+    // The horizon and the row's workspace offsets go through an opaque asm once per pass: everything derived from them
+    // (unroll-remainder predicates of the horizon loops, 64-bit element addresses) is then computed in the phase that uses it.
+    // Hoisted to the kernel entry - they are invariants of this loop - those values lived through every phase and were what
+    // the allocator spilled (predicate pairs into VGPR lanes, addresses into scratch).
+    int T = T0;
+    asm volatile("" : "+s"(T));
+    asm volatile("" : "+v"(Xg.off), "+v"(Ug.off), "+v"(Xo.off), "+v"(Uo.off), "+v"(gains.off));
+    if constexpr (EXACT) asm volatile("" : "+v"(Xalt.off), "+v"(Ualt.off), "+v"(pin_stat.off));
+    FusedProv<S, NX, NU, ORDER> prov;
+    prov.mdl = mdl; prov.Xg = Xg; prov.Ug = Ug; prov.j = j;
     if (__builtin_amdgcn_s_memrealtime() > *wd_slot) {
-#elif M4Q_WD_LDS == 2
-    if (false) {                                   // timing experiment only: no watchdog
-#else
-    if (__builtin_amdgcn_s_memrealtime() - wd_start > a.deadline_ticks) {
-#endif
-      if (threadIdx.x == 0) __hip_atomic_store(a.queue + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (threadIdx.x == 0) __hip_atomic_store(kargs()->queue + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       break;
     }
     // ---- rows without work draw the next item; tail items wait (without blocking) for their head ----
     if (__any(need_new || pending)) {
+      KArgs* a = kargs();
+      const int B = a->B, n_items = two_phase ? 2 * B : B;
+      const int step_begin = a->step_begin, step_end = a->step_end, mf = a->measure_freq;
+      const long sXs = (long)(a->n_steps + 1) * NX, sUs = (long)a->n_steps * NU;
       int nb = 0;
-      if (need_new && jj == 0) nb = atomicAdd(a.queue, 1);
+      if (need_new && jj == 0) nb = __hip_atomic_fetch_add(a->queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       nb = row_bcast_int(nb);
       if (need_new) {
         need_new = false;
         if (nb < n_items) {
-          const bool tail = two_phase && nb >= a.B;
-          b = tail ? nb - a.B : nb;
-          row_begin = tail ? 2 : a.step_begin;
-          row_end = (two_phase && !tail) ? 2 : a.step_end;
+          const bool tail = two_phase && nb >= B;
+          b = tail ? nb - B : nb;
+          row_begin = tail ? 2 : step_begin;
+          row_end = (two_phase && !tail) ? 2 : step_end;
           pending = true;
         }
       }
       // a tail item starts once the head of its instance has been published
       int ready = 1;
       if (pending && two_phase && row_begin == 2 && jj == 0)
-        ready = __hip_atomic_load(a.head_done + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ready = __hip_atomic_load(a->head_done + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       ready = row_bcast_int(ready);
       const bool fresh = pending && ready != 0;
       if (__any(fresh && two_phase && row_begin == 2)) {
@@ -236,11 +268,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
       if (fresh) { pending = false; active = true; }
       wave_sync();
       if (fresh) {
-        stage_model(mdl, static_cast<const S*>(a.models) + b * a.model_stride, jj);
-        xt = gview(x_targ, 0, (unsigned)(b * a.xt_stride));
-        ut = gview(a.u_targ, 0, (unsigned)(b * a.ut_stride));
-        op0 = gview(a.op0, 0, (unsigned)(b * a.op0_stride));
-        ops = gview(a.ops, 0, (unsigned)(b * a.ops_stride));
+        stage_model(mdl, (const M4Q_GLOBAL S*)a->models + b * a->model_stride, jj);
+        xt_off = (unsigned)(b * a->xt_stride) * (unsigned)sizeof(S);
+        ut_off = (unsigned)(b * a->ut_stride) * (unsigned)sizeof(double);
+        op0_off = (unsigned)(b * a->op0_stride) * (unsigned)sizeof(cplx);
+        ops_off = (unsigned)(b * a->ops_stride) * (unsigned)sizeof(cplx);
         step = row_begin;
         iter = 0;
         code = 0;
@@ -249,13 +281,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
       if (__any(fresh && row_begin == 0)) {
         if (fresh && row_begin == 0) {
           // X_guess = tile(x0), U_guess = 0 (mpc.py:141-142); xs[0] = x0 (:160)
-          const S x0 = static_cast<const S*>(a.x0s)[b * NX + j];
+          const S x0 = gld((const M4Q_GLOBAL S*)a->x0s, b * NX + j);
           x_cur = x0;
           x_meas = x0;
           if (lane_ok) {
 #pragma unroll 8
             for (int t = 0; t <= T; ++t) Xg.st<S>(t * NX + j, x0);
-            a.xs[b * sXs + j] = a.x0c[b * NX + j];
+            gst(a->xs, b * sXs + j, gld(a->x0c, b * NX + j));
           }
           for (int e = jj; e < T * NU; e += 16) Ug.st<double>(e, 0.0);
         }
@@ -266,29 +298,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
         const bool rs = fresh && row_begin != 0;
 #pragma unroll 4
         for (int t = 0; t <= T; ++t) {
-          const cplx xc = rs ? a.Xg[b * sX + t * NX + j] : czero();
+          const cplx xc = rs ? gld(a->Xg, b * sX + t * NX + j) : czero();
           const S r = BasisIO<S>::template to_state<NX, DD>(xc, scratch, j, jj);
           if (rs && lane_ok) Xg.st<S>(t * NX + j, r);
         }
-        const cplx xc = rs ? a.xs[b * sXs + (long)row_begin * NX + j] : czero();
+        const cplx xc = rs ? gld(a->xs, b * sXs + (long)row_begin * NX + j) : czero();
         const S r = BasisIO<S>::template to_state<NX, DD>(xc, scratch, j, jj);
-        const cplx xm = rs ? a.xs[b * sXs + (long)(row_begin / mf) * mf * NX + j] : czero();
+        const cplx xm = rs ? gld(a->xs, b * sXs + (long)(row_begin / mf) * mf * NX + j) : czero();
         const S rm = BasisIO<S>::template to_state<NX, DD>(xm, scratch, j, jj);
         if (rs) {
           x_cur = r;
           x_meas = rm;
-          for (int e = jj; e < T * NU; e += 16) Ug.st<double>(e, a.Ug[b * sU + e]);
-          code = a.codes[b];
-          done_steps = a.steps_done[b];
+          for (int e = jj; e < T * NU; e += 16) Ug.st<double>(e, gld(a->Ug, b * sU + e));
+          code = gld(a->codes, b);
+          done_steps = gld(a->steps_done, b);
 #pragma unroll
-          for (int k = 0; k < NU; ++k) uprev[k] = a.us[b * sUs + (long)(row_begin - 1) * NU + k];
+          for (int k = 0; k < NU; ++k) uprev[k] = gld(a->us, b * sUs + (long)(row_begin - 1) * NU + k);
           if (code != 0) step = row_end;          // finished earlier (exit code set by the host or the device)
         }
       }
       wave_sync();
     }
     if (!__any(active || pending)) {
-      if (EXACT && threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 7, (unsigned long long)qp_passes);
+      if (EXACT && threadIdx.x == 0)
+        __hip_atomic_fetch_add((M4Q_GLOBAL unsigned long long*)kargs()->queue + 7, (unsigned long long)qp_passes, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
       break;
     }
     if (!__any(active)) {
@@ -298,103 +332,59 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
     const bool running = active && step < row_end;
 
     // ---- one QP solve per row ----
-    // target window: X_ref = X_targ[:, :T+1] for steps 0 and 1, then X_targ[:, step-1:...] (mpc.py:145,276)
-    const int w = step <= 1 ? 0 : step - 1;
-    Window win;
-    win.xbm = xt.lane<S>((unsigned)w * NX);
-    win.ubm = ut.lane<double>((unsigned)w * NU);
-    double lo0[NU], hi0[NU];
-#pragma unroll
-    for (int k = 0; k < NU; ++k) {
-      // u_prev = us[step-1] if step > 1 else U_ref[:, 0] (mpc.py:185)
-      const double up = step > 1 ? uprev[k] : win.ubm.ld<double>(k);
-      lo0[k] = band ? up - a.du : -a.sat;
-      hi0[k] = band ? up + a.du : a.sat;
-    }
-    const bool use_ls = !(a.warm_start && step > 1);        // mpc.py:208-213
-    const bool st = running && lane_ok;
-    // M4Q_EXP: timing-only ablation builds (results are wrong): 1 fixed 3 SQP iterations, 2 no backward,
-    // 4 no forward, 8 no line search, 16 no guess update, 32 no plant/shift
-    if constexpr (!EXACT && !(M4Q_EXP & 2)) {
-      // (xbar_t the same for every t: the sweep needs no row form of A_t - wave-uniform choice between two instantiations.
-      //  n = 16 only: config 4 85.5 -> 84.2 ms; at n = 9 the kernel with both instantiations is SLOWER, 50.65 -> 51.7 ms,
-      //  although it executes 27 vector instructions fewer per horizon index - profiles/r02_ab_experiments.txt)
-      if (M4Q_TARG_CONST && NX == 16 && (a.flags & QP_TARG_CONST)) riccati_backward<S, NX, NU, FusedProv<S, NX, NU, ORDER>, false, true>(prov, T, win, cost, a.flags, gains, j, st);
-      else if (!MASK_IDLE || lane_ok) riccati_backward<S, NX, NU>(prov, T, win, cost, a.flags, gains, j, st);
-    }
-    wave_sync();
+    // park what the sweeps do not need (the compiler would keep it in scratch across them)
+    stash.put_int(g, jj, 0, (int)(b & 0xffffffff));
+    stash.put_int(g, jj, 1, (int)(b >> 32));
+    stash.put_int(g, jj, 2, code);
+    stash.put_int(g, jj, 3, done_steps);
+    stash.put_int(g, jj, 4, row_begin);
+    stash.put_int(g, jj, 5, (active ? 1 : 0) | (need_new ? 2 : 0) | (pending ? 4 : 0));
+    stash.put_int(g, jj, 6, (int)op0_off);
+    stash.put_int(g, jj, 7, (int)ops_off);
+    stash.put_x(x_meas);
     double uapp[NU];
 #pragma unroll
     for (int k = 0; k < NU; ++k) uapp[k] = 0.0;
     double chk = 0.0;
-    // `solved`: the rows whose QP is solved in this pass and that go on to the line search / update / plant below.
-    // Clipped mode: every running row, each pass.  EXACT: a row's solve spans several passes (one active-set iteration
-    // per pass), so that no row waits for the slowest solve of its wavefront.
-    bool solved = running;
+    bool solved = running;       // the rows whose QP is solved in this pass and that go on to the line search / update / plant below.
+                                 // Clipped mode: every running row, each pass.  EXACT: a row's solve spans several passes (one
+                                 // active-set iteration per pass), so that no row waits for the slowest solve of its wavefront.
     bool capped = false;         // EXACT: the solve stopped at its iteration cap (not converged): exit code 2
-    if constexpr (EXACT) {
-      PinCtx<NU> pin;
-      pin.stat = pin_stat;
-      pin.box.sat = a.sat;
+    bool use_ls;
+    Window win;
+    {
+      KArgs* a = kargs();
+      // target window: X_ref = X_targ[:, :T+1] for steps 0 and 1, then X_targ[:, step-1:...] (mpc.py:145,276)
+      const int w = step <= 1 ? 0 : step - 1;
+      win.xbm = gview((const M4Q_GLOBAL S*)a->x_targ, 0, 0);
+      win.xbm.off = xt_off + (unsigned)w * NX * (unsigned)sizeof(S);
+      win.ubm = gview(a->u_targ, 0, 0);
+      win.ubm.off = ut_off + (unsigned)w * NU * (unsigned)sizeof(double);
+      const double sat = a->sat, du = a->du;
+      double lo0[NU], hi0[NU];
 #pragma unroll
-      for (int k = 0; k < NU; ++k) { pin.lo0[k] = lo0[k]; pin.hi0[k] = hi0[k]; }
-      // rows starting a solve: the current SQP guess (the shifted previous solution on warm steps: nearly the right
-      // working set), clipped into the box and rolled out through the linearised model.  The linearisation point
-      // (Xg, Ug) stays untouched until the solve is over.
-      const bool start = running && !qp.busy;
-      double J0 = 0.0;
-      if (__any(start)) {
-        J0 = rollout_open<S, NX, NU>(prov, T, x_cur, win, cost, Ug, pin.box, lo0, hi0, Xo, Uo, j, start && lane_ok);
-        wave_sync();
+      for (int k = 0; k < NU; ++k) {
+        // u_prev = us[step-1] if step > 1 else U_ref[:, 0] (mpc.py:185)
+        const double up = step > 1 ? uprev[k] : win.ubm.ld<double>(k);
+        lo0[k] = band ? up - du : -sat;
+        hi0[k] = band ? up + du : sat;
       }
-      bool bad_start = false;
-      if (start) {
-        qp.begin(J0);
-        if (!finite_d(J0)) { qp.busy = false; bad_start = true; }
-      }
-      if (__any(qp.busy)) ++qp_passes;
-      const bool ended = box_qp_iterate<S, NX, NU>(prov, T, x_cur, win, cost, a.flags, gains, pin, Xo, Uo, Xalt, Ualt, qp, j, jj, lane_ok);
-      solved = running && (ended || bad_start);
-      capped = solved && !bad_start && qp.stats.end_cap > 0;
-      chk = qp.Jk;
-      GView Xs = Xo, Us = Uo;
-      Xs.off = qp.cur_is_a ? Xo.off : Xalt.off;
-      Us.off = qp.cur_is_a ? Uo.off : Ualt.off;
-      if (solved && jj == 0) {
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 1, 1ull);
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 2, (unsigned long long)qp.stats.sweeps);
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 3, (unsigned long long)qp.stats.ratio_steps);
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 4, (unsigned long long)qp.stats.end_kkt);
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 5, (unsigned long long)qp.stats.end_precision);
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.queue) + 6, (unsigned long long)qp.stats.end_cap);
-      }
-      if (solved && !bad_start) {
-#pragma unroll
-        for (int k = 0; k < NU; ++k) uapp[k] = Us.ld<double>(k);
-        if (use_ls) {
-          // (these copies are latency bound: unrolled so that several loads are in flight)
-          if (!qp.cur_is_a) {
-            if (lane_ok) {
-#pragma unroll 8
-              for (int t = 0; t <= T; ++t) Xo.st<S>(t * NX + j, Xs.ld<S>(t * NX + j));
-            }
-#pragma unroll 4
-            for (int e = jj; e < T * NU; e += 16) Uo.st<double>(e, Us.ld<double>(e));
-          }
-        } else {
-          // warm step (alpha = 1, mpc.py:208-212): the solution becomes the next guess, shifted (mpc.py:271-272)
-          if (lane_ok) {
-#pragma unroll 8
-            for (int t = 0; t <= T; ++t) Xg.st<S>(t * NX + j, Xs.ld<S>((t < T ? t + 1 : T) * NX + j));
-          }
-#pragma unroll 4
-          for (int e = jj; e < T * NU; e += 16) Ug.st<double>(e, Us.ld<double>(e + NU < T * NU ? e + NU : e));
+      use_ls = !(a->warm_start && step > 1);        // mpc.py:208-213
+      const bool st = running && lane_ok;
+      if constexpr (!EXACT) {
+        // (xbar_t the same for every t: the sweep needs no row form of A_t - wave-uniform choice between two instantiations.
+        //  n = 16 real path only: config 4 85.5 -> 84.2 ms; at n = 9 the kernel with both instantiations is SLOWER, 50.65 -> 51.7 ms,
+        //  although it executes 27 vector instructions fewer per horizon index - profiles/r02_ab_experiments.txt)
+        constexpr bool HAS_TC = M4Q_TARG_CONST && NX == 16 && sizeof(S) == sizeof(double);
+        bool tc = false;
+        if constexpr (HAS_TC) tc = (flags & QP_TARG_CONST) != 0;
+        if constexpr (HAS_TC) {
+          if (tc) riccati_backward<S, NX, NU, FusedProv<S, NX, NU, ORDER>, false, true>(prov, T, win, cost, flags, gains, j, st);
         }
-      }
-    } else {
-      if constexpr (!(M4Q_EXP & 4)) {
+        if (!tc && (!MASK_IDLE || lane_ok)) riccati_backward<S, NX, NU>(prov, T, win, cost, flags, gains, j, st);
+        wave_sync();
         if (!MASK_IDLE || lane_ok)
-          chk = rollout_forward<S, NX, NU, false>(prov, T, x_cur, win, cost, a.flags, gains, a.sat, lo0, hi0, Xo, Uo, j, st, uapp,
+          chk = rollout_forward<S, NX, NU, false>(prov, T, x_cur, win, cost, flags, gains, sat, lo0, hi0, Xo, Uo, j, st, uapp,
                                                   !use_ls, &Xg, &Ug);
         if constexpr (MASK_IDLE) {
           // the row's scalars back into the lanes that sat the sweep out
@@ -402,36 +392,105 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
 #pragma unroll
           for (int k = 0; k < NU; ++k) uapp[k] = bcast<0>(uapp[k]);
         }
+      } else {
+        PinCtx<NU> pin;
+        pin.stat = pin_stat;
+        pin.box.sat = sat;
+#pragma unroll
+        for (int k = 0; k < NU; ++k) { pin.lo0[k] = lo0[k]; pin.hi0[k] = hi0[k]; }
+        // rows starting a solve: the current SQP guess (the shifted previous solution on warm steps: nearly the right
+        // working set), clipped into the box and rolled out through the linearised model.  The linearisation point
+        // (Xg, Ug) stays untouched until the solve is over.
+        const bool start = running && !qp.busy;
+        double J0 = 0.0;
+        if (__any(start)) {
+          J0 = rollout_open<S, NX, NU>(prov, T, x_cur, win, cost, Ug, pin.box, lo0, hi0, Xo, Uo, j, start && lane_ok);
+          wave_sync();
+        }
+        bool bad_start = false;
+        if (start) {
+          qp.begin(J0);
+          if (!finite_d(J0)) { qp.busy = false; bad_start = true; }
+        }
+        if (__any(qp.busy)) ++qp_passes;
+        const bool ended = box_qp_iterate<S, NX, NU>(prov, T, x_cur, win, cost, flags, gains, pin, Xo, Uo, Xalt, Ualt, qp, j, jj, lane_ok);
+        solved = running && (ended || bad_start);
+        capped = solved && !bad_start && qp.stats.end_cap > 0;
+        chk = qp.Jk;
+        GView Xs = Xo, Us = Uo;
+        Xs.off = qp.cur_is_a ? Xo.off : Xalt.off;
+        Us.off = qp.cur_is_a ? Uo.off : Ualt.off;
+        if (solved && jj == 0) {
+          M4Q_GLOBAL unsigned long long* cnt = (M4Q_GLOBAL unsigned long long*)kargs()->queue;
+          __hip_atomic_fetch_add(cnt + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_add(cnt + 2, (unsigned long long)qp.stats.sweeps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_add(cnt + 3, (unsigned long long)qp.stats.ratio_steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_add(cnt + 4, (unsigned long long)qp.stats.end_kkt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_add(cnt + 5, (unsigned long long)qp.stats.end_precision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_add(cnt + 6, (unsigned long long)qp.stats.end_cap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (solved && !bad_start) {
+#pragma unroll
+          for (int k = 0; k < NU; ++k) uapp[k] = Us.ld<double>(k);
+          if (use_ls) {
+            // (these copies are latency bound: unrolled so that several loads are in flight)
+            if (!qp.cur_is_a) {
+              if (lane_ok) {
+#pragma unroll 8
+                for (int t = 0; t <= T; ++t) Xo.st<S>(t * NX + j, Xs.ld<S>(t * NX + j));
+              }
+#pragma unroll 4
+              for (int e = jj; e < T * NU; e += 16) Uo.st<double>(e, Us.ld<double>(e));
+            }
+          } else {
+            // warm step (alpha = 1, mpc.py:208-212): the solution becomes the next guess, shifted (mpc.py:271-272)
+            if (lane_ok) {
+#pragma unroll 8
+              for (int t = 0; t <= T; ++t) Xg.st<S>(t * NX + j, Xs.ld<S>((t < T ? t + 1 : T) * NX + j));
+            }
+#pragma unroll 4
+            for (int e = jj; e < T * NU; e += 16) Ug.st<double>(e, Us.ld<double>(e + NU < T * NU ? e + NU : e));
+          }
+        }
       }
     }
     wave_sync();
+    // back from the stash
+    b = ((long)stash.get_int(g, 1) << 32) | (long)(unsigned)stash.get_int(g, 0);
+    code = stash.get_int(g, 2);
+    done_steps = stash.get_int(g, 3);
+    row_begin = stash.get_int(g, 4);
+    {
+      const int fl = stash.get_int(g, 5);
+      active = (fl & 1) != 0; need_new = (fl & 2) != 0; pending = (fl & 4) != 0;
+    }
+    op0_off = (unsigned)stash.get_int(g, 6);
+    ops_off = (unsigned)stash.get_int(g, 7);
+    stash.get_x(x_meas);
     // exit code 3: non-finite objective (mpc.py:200-203).  exit code 2 (EXACT only): the solver gave up - the analogue of
     // the solver warning mpc.py:183-197 turns into code 2; either way the member's run ends here (mpc.py:196,203,231).
-    const bool fail = (M4Q_EXP & (64 | 128 | 512)) ? false : (!finite_d(chk) || capped);
+    const bool fail = !finite_d(chk) || capped;
     if (solved) ++iter;
     double alpha = 1.0;
     bool fin = true;
-    if (!(M4Q_EXP & 8) && __any(solved && use_ls)) {
+    if (__any(solved && use_ls)) {
+      KArgs* a = kargs();
       ZView<NX, NU> z;
       z.T = T; z.Xg = Xg; z.Xo = Xo; z.Xt = win.xbm; z.Ug = Ug; z.Uo = Uo; z.Ut = win.ubm;
       double al = 1.0, stepn = 0.0;
       if (ls_diag) {
         line_search_diag<S, NX, NU, DD>(z, ldsW, ldsW + 2 * NX, ldsW + 4 * NX, jj, al, stepn);
       } else {
-        if constexpr (sizeof(S) == sizeof(cplx)) line_search<NX, NU>(z, a.Cq, a.Cqf, a.Cr, jj, al, stepn);
+        if constexpr (sizeof(S) == sizeof(cplx)) line_search<NX, NU>(z, a->Cq, a->Cqf, a->Cr, jj, al, stepn);
       }
-      if (use_ls) { alpha = al; fin = stepn < a.ls_tol; }   // mpc.py:224
+      if (use_ls) { alpha = al; fin = stepn < a->ls_tol; }   // mpc.py:224
     }
-    if (M4Q_EXP & 1) { fin = !use_ls || iter >= 3; alpha = 1.0; }
     wave_sync();
     const bool upd = solved && !fail && use_ls;       // warm steps wrote the shifted guess in the rollout
     // X_guess += alpha (X_opt - X_guess) (mpc.py:228-229)
     // (these small per-element passes are latency bound: unrolled so that several loads are in flight)
-#ifndef M4Q_UPD_UNROLL
-#define M4Q_UPD_UNROLL 8
-#endif
-    if (!(M4Q_EXP & 16) && upd && lane_ok) {
-#pragma unroll M4Q_UPD_UNROLL
+    if (upd && lane_ok) {
+#pragma unroll 8
       for (int t = 0; t <= T; ++t) {
         const S xg = Xg.ld<S>(t * NX + j), xo = Xo.ld<S>(t * NX + j);
         Xg.st<S>(t * NX + j, cadd(xg, cscale(csub(xo, xg), alpha)));
@@ -444,13 +503,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
         Ug.st<double>(e, ug + alpha * (Uo.ld<double>(e) - ug));
       }
     }
-    const bool step_done = solved && (fail || fin || iter >= a.max_iter);
     wave_sync();
 
     // ---- rows that finished their MPC step: apply, propagate, shift ----
+    bool step_done;
+    {
+      KArgs* a = kargs();
+      step_done = solved && (fail || fin || iter >= a->max_iter);
+    }
     if (__any(step_done)) {
+      KArgs* a = kargs();
+      const int mf = a->measure_freq, n_steps = a->n_steps;
+      const long sXs = (long)(n_steps + 1) * NX, sUs = (long)n_steps * NU;
       if (step_done && fail) code = finite_d(chk) ? 2 : 3;
-      if (step_done && jj == 0) a.qp_solves[b * a.n_steps + step] = iter;
+      if (step_done && jj == 0) gst(a->qp_solves, b * n_steps + step, iter);
       const bool ok = step_done && !fail;
       // apply U_opt[:, 0] (mpc.py:250), propagate the plant (mpc.py:256-260)
       if (ok) {
@@ -458,25 +524,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
         for (int k = 0; k < NU; ++k) uprev[k] = uapp[k];
         if (jj == 0) {
 #pragma unroll
-          for (int k = 0; k < NU; ++k) a.us[b * sUs + (long)step * NU + k] = uapp[k];
+          for (int k = 0; k < NU; ++k) gst(a->us, b * sUs + (long)step * NU + k, uapp[k]);
         }
       }
-      if constexpr (PLANT != PLANT_NONE && !(M4Q_EXP & 32)) {
+      if constexpr (PLANT != PLANT_NONE) {
         // (step+1) % measure_freq == 0: propagate the plant from the last measured state over the last measure_freq
         // intervals (mpc.py:252-260); the held controls are stacked newest first against an increasing time grid
         // (:257), i.e. replayed in reversed order.  Otherwise the model closes the loop (mpc.py:261-267).
         const bool measure = (step + 1) % mf == 0;
         cplx xn = czero();
         if (__any(ok && measure)) {
+          GView op0 = gview(a->op0, 0, 0), ops = gview(a->ops, 0, 0);
+          op0.off = op0_off;
+          ops.off = ops_off;
+          const double dt = a->dt;
           cplx xc = BasisIO<S>::template to_complex<NX, DD>(x_meas, scratch, j, jj);
           wave_sync();
           for (int i = 0; i < mf; ++i) {
             double ui[NU];
 #pragma unroll
             for (int k = 0; k < NU; ++k)
-              ui[k] = (i == 0 || !(ok && measure)) ? uapp[k] : a.us[b * sUs + (long)(step - i) * NU + k];
-            if constexpr (PLANT == PLANT_HAMILTONIAN) xc = plant_hamiltonian<NX, NU, DD>(xc, ui, op0, ops, a.dt, scratch, j, jj);
-            else xc = plant_generator<NX, NU>(xc, ui, op0, ops, a.dt, j);
+              ui[k] = (i == 0 || !(ok && measure)) ? uapp[k] : gld(a->us, b * sUs + (long)(step - i) * NU + k);
+            if constexpr (PLANT == PLANT_HAMILTONIAN) xc = plant_hamiltonian<NX, NU, DD>(xc, ui, op0, ops, dt, scratch, j, jj);
+            else xc = plant_generator<NX, NU>(xc, ui, op0, ops, dt, j);
           }
           xn = xc;
         }
@@ -493,11 +563,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
         }
         if (ok) x_cur = rn;
         if (ok && measure) x_meas = rn;
-        if (ok && lane_ok) a.xs[b * sXs + (long)(step + 1) * NX + j] = xn;
+        if (ok && lane_ok) gst(a->xs, b * sXs + (long)(step + 1) * NX + j, xn);
       }
       // shift_guess (mpc.py:71-73,271-272): drop column 0, repeat the last
       const bool shift_now = ok && use_ls;          // (a warm step's rollout has already shifted)
-      if (!(M4Q_EXP & 32) && shift_now && lane_ok) {
+      if (shift_now && lane_ok) {
         for (int t0 = 0; t0 < T; t0 += 8) {
           S buf[8];
 #pragma unroll
@@ -526,7 +596,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
       if constexpr (PLANT == PLANT_NONE) {
         // the caller writes xs[step+1] before the next launch; inside one launch carry what is there
         const bool carry = ok && step < row_end;
-        const cplx xc = carry ? a.xs[b * sXs + (long)step * NX + j] : czero();
+        const cplx xc = carry ? gld(a->xs, b * sXs + (long)step * NX + j) : czero();
         const S rn = BasisIO<S>::template to_state<NX, DD>(xc, scratch, j, jj);
         if (carry) x_cur = rn;
       }
@@ -535,16 +605,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
     // ---- rows that finished their item: publish the resumable state, free the slot ----
     const bool finished = active && step >= row_end;
     if (__any(finished)) {
+      KArgs* a = kargs();
 #pragma unroll 4
       for (int t = 0; t <= T; ++t) {
         const cplx xc = BasisIO<S>::template to_complex<NX, DD>(Xg.ld<S>(t * NX + j), scratch, j, jj);
-        if (finished && lane_ok) a.Xg[b * sX + t * NX + j] = xc;
+        if (finished && lane_ok) gst(a->Xg, b * sX + t * NX + j, xc);
       }
       if (finished) {
-        for (int e = jj; e < T * NU; e += 16) a.Ug[b * sU + e] = Ug.ld<double>(e);
+        for (int e = jj; e < T * NU; e += 16) gst(a->Ug, b * sU + e, Ug.ld<double>(e));
         if (jj == 0) {
-          a.codes[b] = code;
-          a.steps_done[b] = done_steps;
+          gst(a->codes, b, code);
+          gst(a->steps_done, b, done_steps);
         }
       }
       if (two_phase && __any(finished && row_end == 2)) {
@@ -555,7 +626,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (finished && row_end == 2 && jj == 0)
-          __hip_atomic_store(a.head_done + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(a->head_done + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       if (finished) {
         active = false;
@@ -617,8 +688,9 @@ __global__ __launch_bounds__(64) M4Q_OCC void qp_kernel(QpArgs a) {
   const int T = a.T;
   const int nquads = (a.B + ROWS - 1) / ROWS;
   CostRef<cplx> cost;
-  cost.Q = a.Q_ls; cost.Qf = a.Q_ls + (long)T * NX * NX; cost.q_stride = (long)NX * NX;
-  cost.R = a.R_ls; cost.r_stride = (long)NU * NU;
+  // (stage costs of the explicit QP stay in global memory: generic pointers the compiler traces back to the kernel argument)
+  cost.Q = (const cplx*)a.Q_ls; cost.Qf = (const cplx*)a.Q_ls + (long)T * NX * NX; cost.q_stride = (long)NX * NX;
+  cost.R = (const cplx*)a.R_ls; cost.r_stride = (long)NU * NU;
   const unsigned sX = (unsigned)(T + 1) * NX, sU = (unsigned)T * NU, sG = (unsigned)T * (NX + 1) * NU;
   const unsigned sA = (unsigned)T * NX * NX, sB = (unsigned)T * NX * NU, sD = (unsigned)T * NX;
   for (int quad = blockIdx.x; quad < nquads; quad += gridDim.x) {
@@ -645,11 +717,11 @@ __global__ __launch_bounds__(64) M4Q_OCC void qp_kernel(QpArgs a) {
 #pragma unroll
     for (int k = 0; k < NU; ++k) {
       const bool band = (a.flags & QP_DU_BAND) != 0 && a.u_prev != nullptr;
-      const double up = band ? a.u_prev[b * NU + k] : 0.0;
+      const double up = band ? gld(a.u_prev, b * NU + k) : 0.0;
       lo0[k] = band ? up - a.du : -a.sat;
       hi0[k] = band ? up + a.du : a.sat;
     }
-    const cplx x0 = a.x_init[b * NX + j];
+    const cplx x0 = gld(a.x_init, b * NX + j);
     const bool exact = (a.flags & QP_EXACT_BOX) != 0;
     // the exact solver ping-pongs between two trajectory pairs of ONE allocation (rows pick theirs by lane offset):
     // X_alt = [B][T+1][n] twice, U_alt likewise; the clipped rollout, its starting point, goes straight into the first
@@ -681,10 +753,10 @@ __global__ __launch_bounds__(64) M4Q_OCC void qp_kernel(QpArgs a) {
         if (j == 0)
           for (int i = 0; i < T * NU; ++i) Uo.st<double>(i, Us.ld<double>(i));
       }
-      if (valid && jj == 0 && a.sweep_counts) a.sweep_counts[b] = stats.sweeps;
+      if (valid && jj == 0 && a.sweep_counts) gst(a.sweep_counts, b, stats.sweeps);
       wave_sync();
     }
-    if (valid && jj == 0) a.cost[b] = obj_out;
+    if (valid && jj == 0) gst(a.cost, b, obj_out);
   }
 }
 
@@ -703,10 +775,10 @@ __global__ __launch_bounds__(64) M4Q_OCC void plant_kernel(PlantArgs a) {
     const bool valid = q0 + g < a.B;
     const unsigned gl = valid ? g : (unsigned)(a.B - 1 - q0);
     const long b = q0 + gl;
-    const cplx x = a.x[b * NX + j];
+    const cplx x = gld(a.x, b * NX + j);
     double u[NU];
 #pragma unroll
-    for (int k = 0; k < NU; ++k) u[k] = a.u[b * NU + k];
+    for (int k = 0; k < NU; ++k) u[k] = gld(a.u, b * NU + k);
     const GView op0 = gview(a.op0, q0 * a.op0_stride, gl * (unsigned)a.op0_stride);
     const GView ops = gview(a.ops, q0 * a.ops_stride, gl * (unsigned)a.ops_stride);
     cplx xn;
@@ -714,7 +786,7 @@ __global__ __launch_bounds__(64) M4Q_OCC void plant_kernel(PlantArgs a) {
       xn = plant_hamiltonian<NX, NU, DD>(x, u, op0, ops, a.dt, scratch, j, jj);
     else
       xn = plant_generator<NX, NU>(x, u, op0, ops, a.dt, j);
-    if (valid && jj < NX) a.x_next[b * NX + j] = xn;
+    if (valid && jj < NX) gst(a.x_next, b * NX + j, xn);
   }
 }
 
@@ -750,19 +822,19 @@ __global__ __launch_bounds__(64) void discretize_kernel(DiscArgs a) {
   constexpr int W = NX * (1 + NP);
   S* G = lds + g * GEN_ELEMS;                      // [1+m][n][n] row-major, scaled
   const int nquads = (a.B + ROWS - 1) / ROWS;
-  const S* gens = static_cast<const S*>(a.gens);
-  S* models = static_cast<S*>(a.models);
+  const M4Q_GLOBAL S* gens = (const M4Q_GLOBAL S*)a.gens;
+  M4Q_GLOBAL S* models = (M4Q_GLOBAL S*)a.models;
   for (int quad = blockIdx.x; quad < nquads; quad += gridDim.x) {
     const long q0 = (long)quad * ROWS;
     const bool valid = q0 + g < a.B;
     const long b = valid ? q0 + g : a.B - 1;
     wave_sync();
     for (int e = jj; e < GEN_ELEMS; e += 16) {
-      const double sc = a.scales ? a.scales[b * (1 + NU) + e / (NX * NX)] : 1.0;
-      G[e] = cscale(gens[b * a.gen_stride + e], sc);
+      const double sc = a.scales ? gld(a.scales, b * (1 + NU) + e / (NX * NX)) : 1.0;
+      G[e] = cscale(gld(gens, b * a.gen_stride + e), sc);
     }
     wave_sync();
-    S* out = models + b * (long)NX * W;
+    M4Q_GLOBAL S* out = models + b * (long)NX * W;
     // accumulate every block's column j in registers: blk[p][i]
     S blk[1 + NP][NX];
 #pragma unroll
@@ -796,7 +868,7 @@ __global__ __launch_bounds__(64) void discretize_kernel(DiscArgs a) {
 #pragma unroll
       for (int p = 0; p <= NP; ++p)
 #pragma unroll
-        for (int i = 0; i < NX; ++i) out[i * W + p * NX + j] = blk[p][i];
+        for (int i = 0; i < NX; ++i) gst(out, i * W + p * NX + j, blk[p][i]);
     }
   }
 }

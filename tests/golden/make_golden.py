@@ -433,8 +433,10 @@ def long_cases():
 def golden_mpc_long():
     """(7) the reference's mpc() at the BASELINE horizons (mpc_loop.npz stops at T = 12), same harness as (6), plus the
     reference's OWN sensitivity: for every MPC step k the run is repeated with the linearisation point of step k's first QP solve
-    scaled by 1 + 1e-15; sens_us[k] = max |us[k] - us_perturbed[k]|, sens_xs[k] likewise for xs[k+1].  A step whose outputs the
-    reference itself does not determine beyond sens cannot be held tighter by anything compared with it."""
+    scaled by 1 + 1e-15; sens_us[k] = max |us[k] - us_perturbed[k]|, sens_xs[k] likewise for xs[k+1], sens_xg[k] the relative
+    change of the SQP guess the reference starts step k+1 from.  A step whose outputs the reference itself does not determine
+    beyond sens cannot be held tighter by anything compared with it.  env_us / env_xs: the free-running envelope - the running
+    maximum, over MPC steps, of how far the reference's whole run moves when x0 is scaled by 1 +- 1e-14."""
     ref = load_reference_mpc()
     log, hook = install_recorder(ref)
     out = {}
@@ -442,19 +444,39 @@ def golden_mpc_long():
     for name, c in long_cases().items():
         names.append(name)
         xs, us, code = run_loop_case(ref, log, hook, name, c, out)
-        ns = c["n_steps"]
-        sens_u, sens_x = np.zeros(ns), np.zeros(ns)
+        ns, dt = c["n_steps"], c["dt"]
+        base_steps = np.array([int(round(t0 / dt)) for t0, _, _ in log], dtype=np.int32)
+        base_Xg = [xg for _, xg, _ in log]
+        sens_u, sens_x, sens_g = np.zeros(ns), np.zeros(ns), np.zeros(ns)
         for k in range(ns):
             hook["perturb_step"] = k
-            xs_p, us_p, code_p = run_loop_case(ref, log, hook, name, c, out, record=False, n_steps=k + 1)
+            last = k + 1 == ns
+            xs_p, us_p, code_p = run_loop_case(ref, log, hook, name, c, out, record=False, n_steps=k + 1 if last else k + 2)
             hook["perturb_step"] = None
-            assert code_p == 0 and us_p.shape[1] == k + 1
+            assert code_p == 0 and us_p.shape[1] >= k + 1
             assert k == 0 or np.array_equal(us_p[:, :k], us[:, :k])           # identical up to the perturbed step
             sens_u[k] = np.abs(us_p[:, k] - us[:, k]).max()
             sens_x[k] = np.abs(xs_p[:, k + 1] - xs[:, k + 1]).max()
+            if not last:
+                # the guess the reference starts step k+1 from (handed to get_model_along_traj at that step's first solve)
+                pert_steps = [int(round(t0 / dt)) for t0, _, _ in log]
+                xg_p = log[pert_steps.index(k + 1)][1]
+                xg_0 = base_Xg[int(np.nonzero(base_steps == k + 1)[0][0])]
+                sens_g[k] = np.abs(xg_p - xg_0).max() / max(1.0, np.abs(xg_0).max())
         out["loop_" + name + "_sens_us"], out["loop_" + name + "_sens_xs"] = sens_u, sens_x
-        print("   reference's own sensitivity to 1e-15 in the guess: max over steps  us %.2e  xs %.2e" % (sens_u.max(), sens_x.max()))
+        out["loop_" + name + "_sens_xg"] = sens_g
+        print("   reference's own sensitivity to 1e-15 in the guess: max over steps  us %.2e  xs %.2e  next guess (relative) %.2e"
+              % (sens_u.max(), sens_x.max(), sens_g.max()))
         print("   per step us:", " ".join("%.1e" % v for v in sens_u))
+        # free-running envelope: how far the reference's whole run moves when x0 is scaled by 1 +- 1e-14 (running maximum over steps)
+        env_u, env_x = np.zeros(ns), np.zeros(ns + 1)
+        for scale in (1 + 1e-14, 1 - 1e-14, 1 + 7e-14):
+            xs_p, us_p, code_p = run_loop_case(ref, log, hook, name, dict(c, x0_scale=scale), out, record=False)
+            assert code_p == 0
+            env_u = np.maximum(env_u, np.maximum.accumulate(np.abs(us_p - us).max(axis=0)))
+            env_x = np.maximum(env_x, np.maximum.accumulate(np.abs(xs_p - xs).max(axis=0)))
+        out["loop_" + name + "_env_us"], out["loop_" + name + "_env_xs"] = env_u, env_x
+        print("   free-running envelope (x0 scaled by 1 +- 1e-14): us per step", " ".join("%.1e" % v for v in env_u))
     out["loop_names"] = np.array(names)
     np.savez_compressed(os.path.join(OUT, "mpc_loop_long.npz"), **out)
     print("wrote mpc_loop_long.npz")

@@ -276,19 +276,25 @@ def test_mpc_loop_teacher_forced_vs_reference_mpc_py(golden, name):
         assert np.abs(xs[:, k + 1] - c["xs"][:, k + 1]).max() <= 1e-11 + 10 * sx[k], k
 
 
-@pytest.mark.parametrize("name", LOOPS_OK)
+@pytest.mark.parametrize("name", LOOPS_OK + LOOPS_LONG)
 def test_mpc_loop_free_running_vs_reference_mpc_py(golden, name):
     """The whole run: same exit code, same returned shapes, same clock.ts_sim, same QP-solve schedule.  Steps 0 and 1
     (all their SQP iterations) to 1e-10; later steps within what the loop's conditioning allows (controls saturate, so
     differences in the last bits of a bang-bang switch grow) - bounded loosely here, tightly by the teacher-forced test."""
-    c = loop_case(golden("mpc_loop"), name)
+    c = loop_case(golden(_which(name)), name)
     tr = []
     xs, us, code, clock = oracle_loop(c, solve_trace=tr)
     assert code == int(c["exit_code"]) and xs.shape == c["xs"].shape and us.shape == c["us"].shape
     assert np.array_equal(clock.ts_sim, c["ts_sim"])
     assert np.array_equal(np.array([s for s, _, _ in tr]), c["solve_step"])
     assert np.abs(us[:, :2] - c["us"][:, :2]).max() <= 1e-10 and np.abs(xs[:, :3] - c["xs"][:, :3]).max() <= 1e-10
-    assert np.abs(us - c["us"]).max() <= 1e-6 * c["sat"] and np.abs(xs - c["xs"]).max() <= 1e-6
+    if "env_us" in c:
+        # BASELINE horizons: held to the REFERENCE's own free-running envelope (its run with x0 scaled by 1 +- 1e-14; at T = 40 the
+        # reference's loop is chaotic from step 7 on: a bang-bang switch flips, 3.1 = 2 sat by step 13)
+        assert np.all(np.abs(us - c["us"]).max(axis=0) <= 1e-9 + 100 * c["env_us"])
+        assert np.all(np.abs(xs - c["xs"]).max(axis=0) <= 1e-9 + 100 * c["env_xs"])
+    else:
+        assert np.abs(us - c["us"]).max() <= 1e-6 * c["sat"] and np.abs(xs - c["xs"]).max() <= 1e-6
 
 
 @pytest.mark.parametrize("name", ["qubit_o1_exit_step3", "qubit_o1_exit_step0"])
