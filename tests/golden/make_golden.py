@@ -433,8 +433,8 @@ def long_cases():
 def golden_mpc_long():
     """(7) the reference's mpc() at the BASELINE horizons (mpc_loop.npz stops at T = 12), same harness as (6), plus the
     reference's OWN sensitivity: for every MPC step k the run is repeated with the linearisation point of step k's first QP solve
-    scaled by 1 + 1e-15; sens_us[k] = max |us[k] - us_perturbed[k]|, sens_xs[k] likewise for xs[k+1], sens_xg[k] the relative
-    change of the SQP guess the reference starts step k+1 from.  A step whose outputs the reference itself does not determine
+    scaled by 1 + 1e-15; sens_us[k] = max |us[k] - us_perturbed[k]|, sens_xs[k] likewise for xs[k+1], sens_xg[k] / sens_ug[k] the relative
+    change of the SQP guess (states / controls) the reference starts step k+1 from.  A step whose outputs the reference itself does not determine
     beyond sens cannot be held tighter by anything compared with it.  env_us / env_xs: the free-running envelope - the running
     maximum, over MPC steps, of how far the reference's whole run moves when x0 is scaled by 1 +- 1e-14."""
     ref = load_reference_mpc()
@@ -447,7 +447,8 @@ def golden_mpc_long():
         ns, dt = c["n_steps"], c["dt"]
         base_steps = np.array([int(round(t0 / dt)) for t0, _, _ in log], dtype=np.int32)
         base_Xg = [xg for _, xg, _ in log]
-        sens_u, sens_x, sens_g = np.zeros(ns), np.zeros(ns), np.zeros(ns)
+        base_Ug = [ug for _, _, ug in log]
+        sens_u, sens_x, sens_g, sens_gu = np.zeros(ns), np.zeros(ns), np.zeros(ns), np.zeros(ns)
         for k in range(ns):
             hook["perturb_step"] = k
             last = k + 1 == ns
@@ -460,13 +461,15 @@ def golden_mpc_long():
             if not last:
                 # the guess the reference starts step k+1 from (handed to get_model_along_traj at that step's first solve)
                 pert_steps = [int(round(t0 / dt)) for t0, _, _ in log]
-                xg_p = log[pert_steps.index(k + 1)][1]
-                xg_0 = base_Xg[int(np.nonzero(base_steps == k + 1)[0][0])]
+                xg_p, ug_p = log[pert_steps.index(k + 1)][1:]
+                i0 = int(np.nonzero(base_steps == k + 1)[0][0])
+                xg_0, ug_0 = base_Xg[i0], base_Ug[i0]
                 sens_g[k] = np.abs(xg_p - xg_0).max() / max(1.0, np.abs(xg_0).max())
+                sens_gu[k] = np.abs(ug_p - ug_0).max() / max(1.0, np.abs(ug_0).max())
         out["loop_" + name + "_sens_us"], out["loop_" + name + "_sens_xs"] = sens_u, sens_x
-        out["loop_" + name + "_sens_xg"] = sens_g
-        print("   reference's own sensitivity to 1e-15 in the guess: max over steps  us %.2e  xs %.2e  next guess (relative) %.2e"
-              % (sens_u.max(), sens_x.max(), sens_g.max()))
+        out["loop_" + name + "_sens_xg"], out["loop_" + name + "_sens_ug"] = sens_g, sens_gu
+        print("   reference's own sensitivity to 1e-15 in the guess: max over steps  us %.2e  xs %.2e  next guess (relative) X %.2e U %.2e"
+              % (sens_u.max(), sens_x.max(), sens_g.max(), sens_gu.max()))
         print("   per step us:", " ".join("%.1e" % v for v in sens_u))
         # free-running envelope: how far the reference's whole run moves when x0 is scaled by 1 +- 1e-14 (running maximum over steps)
         env_u, env_x = np.zeros(ns), np.zeros(ns + 1)

@@ -1168,6 +1168,7 @@ def test_mpc_loop_teacher_forced_vs_reference_mpc_py(golden, name, path):
     n, m, T, ns = c["d"] ** 2, c["m"], c["T"], c["n_steps"]
     steps, Xg, Ug = c["solve_step"], c["solve_Xg"], c["solve_Ug"]
     su, sx, sg = c.get("sens_us", np.zeros(ns)), c.get("sens_xs", np.zeros(ns)), c.get("sens_xg", np.zeros(ns))
+    sgu = c.get("sens_ug", np.zeros(ns))
     exp = _ref_plant(c)
     op0, ops = exp.operators()
     sess = m4q.EnsembleSession(1, n, m, c["order"], T, ns, c["dt"], c["sat"], c["du"], c["max_iter"], c["warm_start"],
@@ -1194,7 +1195,7 @@ def test_mpc_loop_teacher_forced_vs_reference_mpc_py(golden, name, path):
                 nxt = np.nonzero(steps == k + 1)[0][0]
                 # (T = 80: the far end of the guess reaches 1e13 and the reference itself moves it by 2e-3, relative, under a 1e-15
                 #  perturbation - sens_xg; the step's outputs above are what the loop applies)
-                assert rel(got["x_guess"][0], Xg[nxt].T) <= 1e-7 + 10 * sg[k] and rel(got["u_guess"][0], Ug[nxt].T) <= 1e-7 + 10 * sg[k], k
+                assert rel(got["x_guess"][0], Xg[nxt].T) <= 1e-7 + 10 * sg[k] and rel(got["u_guess"][0], Ug[nxt].T) <= 1e-7 + 10 * sgu[k], k
     finally:
         sess.close()
 
