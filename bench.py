@@ -28,13 +28,22 @@ PEAK_F64_TFLOPS = 78.6      # MI355X fp64 dense rate (AMD spec; 256 CU x 4 SIMD 
                             # DPP row broadcasts) and v_mfma_f64 run on the SAME pipe at the same rate: tools/ubench_mfma.hip measures
                             # 76-78 TFLOP/s for either and the SUM when both are issued (profiles/r02_ubench_mfma.txt)
 PEAK_HBM_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md
-PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r03_pmc.json")
 
 
-def executed_flop_per_hstep(n, path):
-    """Arithmetic the selected path executes per horizon-step: the real (Hermitian-basis) path runs the same recursion on
-    real numbers, a quarter of the real flops of the complex one."""
-    return ALG_FLOP[n] / (4.0 if path == "real" else 1.0)
+def mac_per_hstep(n, m, P):
+    """Multiply-accumulates of one horizon index of one QP solve on n coordinates (linearise (2P + 2) n^2,
+    Riccati 2 N^3 + 4 m N^2 with N = n + 1, forward n^2 + n m + m N)."""
+    N = n + 1
+    return (2 * P + 2) * n * n + 2 * N ** 3 + 4 * m * N * N + n * n + n * m + m * N
+
+
+def executed_flop_per_hstep(n, m, P, path):
+    """Arithmetic the selected path EXECUTES per horizon-step: complex recursion on n = d*d coordinates (8 flop per complex MAC),
+    the same recursion on real numbers in the Hermitian basis (2 flop per MAC), or on the n - 1 traceless coordinates."""
+    if path == "complex":
+        return 8.0 * mac_per_hstep(n, m, P)
+    return 2.0 * mac_per_hstep(n - 1 if path.startswith("traceless") else n, m, P)
 
 
 def compulsory_bytes(B, n, m, P, T, ns, path):
@@ -51,7 +60,7 @@ def pmc_record(key, avg_launch_ms):
     try:
         rec = json.load(open(PMC_JSON))[key]
     except Exception:
-        return None, "no counter record for %s in profiles/r02_pmc.json" % key
+        return None, "no counter record for %s in profiles/r03_pmc.json" % key
     # like for like: the HIP-event launch time bench.py itself measured in the record's traced run (rocprofv3's own kernel-trace
     # average of that run, 1 % higher, is kept beside it and must agree: tests/test_bench_logic.py)
     ref = rec.get("hip_event_launch_ms_same_run") or rec.get("traced_avg_launch_ms") or 0.0
@@ -207,7 +216,8 @@ def main():
     else:
         models = p["models"] if p["models"] is not None else configs.build(args.config, batch=1)["models"]
     sess.load_problem(models, p["x0"], p["X_targ"], p["U_targ"], p["Q"], p["R"], p["Qf"], p["plant_op0"], p["plant_ops"])
-    path = sess.path()
+    path = sess.path()                  # "real" / "complex": the dtype of the arithmetic
+    detail = sess.path_detail()         # "complex" | "real" (d*d Hermitian coordinates) | "traceless" (d*d - 1) | "traceless-tile"
 
     runs = [0]
 
@@ -243,6 +253,8 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms, launches = sess.kernel_ms()
 
+    if os.environ.get("M4Q_PHASE_TRACE"):
+        sess.qp_stats()              # development builds (-DM4Q_DEV_PHASE_CLOCK): prints the wavefront time per phase of the main loop
     res = sess.results()
     units_per_step = int(res["qp_solves"].astype(np.int64).sum()) * T
     ok = int((res["exit_codes"] == 0).sum())
@@ -263,10 +275,14 @@ def main():
         # units of arithmetic per launch: horizon-steps; in the exact mode one pinned sweep + policy rollout over the horizon
         # is the arithmetic of one clipped solve
         hsteps = T * qp_stats[1] if qp_stats else units_per_step
-        flops_exec = executed_flop_per_hstep(n, path) * hsteps
+        flops_exec = executed_flop_per_hstep(n, m, P, detail) * hsteps
         flops_alg = ALG_FLOP[n] * hsteps
         cbytes = compulsory_bytes(B, n, m, P, T, ns, path)
         key = "config%d_B%d_%s_%s" % (args.config, B, path, "exact" if args.exact_qp else "clip")
+        if detail == "real":
+            key += "_real9"
+        if detail == "traceless-tile":
+            key += "_tile"
         rec, why = pmc_record(key, 1e3 * avg_launch_s)
         traffic = issue = None
         if rec:
@@ -284,7 +300,7 @@ def main():
                          "fma_share_of_valu_insts": c["SQ_INSTS_VALU_FMA_F64"] / c["SQ_INSTS_VALU"] if "SQ_INSTS_VALU" in c else None,
                          "wave_time_waiting": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"] if "SQ_WAVE_CYCLES" in c else None,
                          "clock_ghz_under_load": cycles / (pmc_ms * 1e-3) / 1e9,
-                         "note": "from profiles/r02_pmc.json (separate --pmc passes on this binary); all 64 lanes counted"}
+                         "note": "from profiles/r03_pmc.json (separate --pmc passes on this binary); all 64 lanes counted"}
         out = {
             "metric": "MPC horizon-steps/sec across batch (3-level transmon, T=40)" if args.config == 3
                       else "MPC horizon-steps/sec across batch (config %d)" % args.config,
@@ -292,7 +308,7 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64" if path == "real" else "c128", "data": "synthetic",
             "config": {"workload": "BASELINE config %d: d=%d (n=%d, m=%d), order %d, T=%d, n_steps=%d, %d ensemble members per GPU, "
-                                   "per-instance models, full closed loop per step; %s arithmetic path" % (args.config, p["d"], n, m, p["order"], T, ns, B, path),
+                                   "per-instance models, full closed loop per step; %s arithmetic path (%s)" % (args.config, p["d"], n, m, p["order"], T, ns, B, path, detail),
                        "batch_per_gpu": B, "horizon": T, "n_steps": ns, "qp_solves_per_step": units_per_step // T,
                        "instances_ok": ok_total, "parallelism": "ensemble-sharded x%d, one gather" % world,
                        "grid": info["grid"], "lds_bytes": info["lds_bytes"], "hbm_resident_bytes": info["hbm_bytes"],
@@ -304,7 +320,7 @@ def main():
                          "kernel": "mpc_kernel<%s, PLANT_HAMILTONIAN, %s>" % ("double" if path == "real" else "cplx",
                                                                               "true" if args.exact_qp else "false"),
                          "launches": launches, "avg_launch_ms": 1e3 * avg_launch_s,
-                         "flop_per_horizon_step": executed_flop_per_hstep(n, path), "horizon_steps_per_launch": hsteps,
+                         "flop_per_horizon_step": executed_flop_per_hstep(n, m, P, detail), "horizon_steps_per_launch": hsteps,
                          "note": "compute-bound kernel: intensity >> the fp64 machine balance, so the binding roof is fp64 FMA issue "
                                  "(v_fma_f64 with DPP row broadcasts; no MFMA instruction is executed - fp64 MFMA shares this pipe and "
                                  "peak).  achieved = flops of the arithmetic the selected path EXECUTES (real path: a quarter of SURVEY "
@@ -316,7 +332,7 @@ def main():
                          "hbm": {"achieved": cbytes / avg_launch_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": cbytes / avg_launch_s / 1e9 / PEAK_HBM_GBS, "compulsory_bytes": cbytes,
                                  "note": "compulsory bytes of the persistent launch (models, states and guesses once per run)"},
-                         "traffic_note": why or "FETCH_SIZE/WRITE_SIZE of profiles/r02_pmc.json, taken on this binary (launch time "
+                         "traffic_note": why or "FETCH_SIZE/WRITE_SIZE of profiles/r03_pmc.json, taken on this binary (launch time "
                                                 "within 3 %): L2-miss bytes per launch, mostly served by the Infinity Cache"},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -62,6 +62,16 @@ extern "C" {
  * that basis with real arithmetic - a quarter of the flops of the complex recursion of lqr.py, same results to
  * rounding; anything else runs the general complex path.  This bit forces the complex path. */
 #define M4Q_OPT_FORCE_COMPLEX 1
+/* A real-path session whose model also leaves the identity component of rho alone (trace-preserving and unital: every
+ * vectorised Liouvillian -i[H, .] and its Taylor truncation) and whose initial states and targets share one trace runs the
+ * recursion on the d*d - 1 traceless Hermitian coordinates - one dimension fewer, same results to rounding.  This bit keeps
+ * such a session on the d*d-coordinate real path. */
+#define M4Q_OPT_NO_TRACELESS 2
+/* Experimental: a traceless session with a constant target over the horizon window runs the two sweeps of the clipped solve
+ * on fp64 matrix-core tiles (v_mfma_f64_4x4x4_4b_f64, csrc/m4q_tile.h) instead of DPP rows.  Same results to rounding; on
+ * MI355X it is SLOWER than the DPP sweeps today (config 3: 54 against 47 ms - the tile rollout is bound by workspace latency,
+ * profiles/r03_tile_log.txt), so it is off unless this bit (or M4Q_TILE=1 in the environment) asks for it. */
+#define M4Q_OPT_TILE 4
 
 /* exit codes per instance (mpc.py:130,195,202,291): 0 normal, 1 exit_condition (host side),
  * 2 solver gave up (mpc.py:183-197 turns a cvxpy/OSQP warning into this; here: an M4Q_QP_EXACT_BOX solve that stopped at
@@ -83,7 +93,7 @@ typedef struct m4q_problem {
   int32_t plant_per_instance;
   int32_t target_per_instance;
   int32_t target_cols; /* columns of X_targ; U_targ has the same count (extra ones unused) */
-  int32_t reserved;    /* options: bit 0 = M4Q_OPT_FORCE_COMPLEX */
+  int32_t reserved;    /* options: M4Q_OPT_FORCE_COMPLEX | M4Q_OPT_NO_TRACELESS | M4Q_OPT_TILE */
   int32_t measure_freq; /* StepClock.measure_freq (mpc.py:19,252-267): the plant is measured every measure_freq-th step, the
                            model closes the loop in between; 0 or 1 = every step */
   int32_t reserved2;
@@ -195,7 +205,8 @@ M4Q_API int m4q_session_sync(m4q_session* s);
 M4Q_API int m4q_session_set_codes(m4q_session* s, const int32_t* codes);
 /* kernel time of the launches since the last call, from HIP events on the session stream */
 M4Q_API int m4q_session_kernel_ms(m4q_session* s, double* total_ms, int32_t* launches);
-/* 1 if the uploaded problem qualifies for (and will run on) the real-arithmetic path, else 0 */
+/* arithmetic path the uploaded problem will run on: 0 complex, 1 real (Hermitian operator basis, d*d coordinates),
+ * 2 real on the d*d - 1 traceless coordinates, 3 the same with the sweeps on matrix-core tiles */
 M4Q_API int m4q_session_path(const m4q_session* s);
 /* M4Q_QP_EXACT_BOX sessions: counters of the last launch - out[0] QP solves, out[1] Riccati sweeps with pinned
  * controls, out[2] ratio-test steps, out[3..5] solves ended by the KKT test / at working precision / by the iteration

@@ -16,7 +16,7 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(PKG, "libm4q_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-command-line-argument"]
-HEADERS = ["m4q_device.h", "m4q_dpp_gen.h", "m4q_mpc.h", "m4q_args.h", "m4q_shapes.inc",
+HEADERS = ["m4q_device.h", "m4q_dpp_gen.h", "m4q_mpc.h", "m4q_tile.h", "m4q_args.h", "m4q_shapes.inc",
            os.path.join("..", "..", "include", "m4q.h")]
 STAMP = os.path.join(OBJ, "flags.stamp")       # the extra flags the objects in OBJ were built with
 
@@ -84,10 +84,15 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--jobs", type=int, default=None)
-    ap.add_argument("--shfl", action="store_true", help="debug build: row broadcasts through ds_bpermute instead of DPP")
+    ap.add_argument("--dev", action="store_true", help="development build (-DM4Q_DEV): required for --shfl and for any --define of a "
+                                                       "development switch; the sources refuse those switches without it")
+    ap.add_argument("--shfl", action="store_true", help="debug build (needs --dev): row broadcasts through ds_bpermute instead of DPP")
     ap.add_argument("--define", action="append", default=[], help="extra -D for the kernel objects (tuning experiments; forces a rebuild)")
     ap.add_argument("--flag", action="append", default=[], help="extra compiler flag for the kernel objects, e.g. "
                                                                 "--flag=-mllvm --flag=-amdgpu-sched-strategy=max-ilp (forces a rebuild)")
     a = ap.parse_args()
-    extra = (["-DM4Q_BCAST_SHFL"] if a.shfl else []) + ["-D" + d for d in a.define] + list(a.flag)
+    dev_names = ("M4Q_BCAST_SHFL", "M4Q_NOP", "M4Q_DEV_PHASE_CLOCK", "M4Q_TWO_INDEX_COMPLEX", "M4Q_EXP")
+    if not a.dev and (a.shfl or any(d.split("=")[0] in dev_names for d in a.define)):
+        sys.exit("development switches need --dev (the library they produce is not the product)")
+    extra = (["-DM4Q_DEV"] if a.dev else []) + (["-DM4Q_BCAST_SHFL"] if a.shfl else []) + ["-D" + d for d in a.define] + list(a.flag)
     print(build(a.force or bool(extra), a.jobs, extra))

@@ -167,6 +167,62 @@ struct LiftStat {
   bool real_enough() const { return max_im <= 1e-13 * std::max(1.0, max_abs); }
 };
 
+// ---- traceless coordinates (path 2; csrc/m4q_mpc.h): the diagonal slots (a, a) of the Hermitian basis rotated by the orthogonal
+// O[a][0] = 1/sqrt(d), O[a][l] = 1/sqrt(l(l+1)) (a < l), -l/sqrt(l(l+1)) (a == l), 0 (a > l); slot (0, 0) becomes the trace
+// coordinate and is dropped when the model leaves it alone.  Works on the REAL arrays the Hermitian lift produced.
+struct Traceless {
+  int d, n;
+  std::vector<double> O;                 // n x n: identity off the diagonal slots
+  explicit Traceless(int d_) : d(d_), n(d_ * d_), O((size_t)d_ * d_ * d_ * d_, 0.0) {
+    for (int c = 0; c < n; ++c) O[(size_t)c * n + c] = 1.0;
+    for (int a = 0; a < d; ++a)
+      for (int l = 0; l < d; ++l) {
+        double v;
+        if (l == 0) v = 1.0 / std::sqrt((double)d);
+        else v = a < l ? 1.0 / std::sqrt((double)l * (l + 1)) : (a == l ? -(double)l / std::sqrt((double)l * (l + 1)) : 0.0);
+        O[(size_t)(a * d + a) * n + (l * d + l)] = v;
+      }
+  }
+  // r (n) -> O^T r: out[0] = trace coordinate, out[1..n) = traceless coordinates
+  void vec(const double* r, double* out) const {
+    for (int c = 0; c < n; ++c) {
+      double acc = 0.0;
+      for (int k = 0; k < n; ++k) acc += O[(size_t)k * n + c] * r[k];
+      out[c] = acc;
+    }
+  }
+  // M (n x n, leading dimension ld) -> O^T M O (n x n, dense, into out)
+  void mat(const double* M, long ld, double* out) const {
+    std::vector<double> Y((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i)
+      for (int k = 0; k < n; ++k) {
+        const double m = M[i * ld + k];
+        if (m != 0.0)
+          for (int c = 0; c < n; ++c) Y[(size_t)i * n + c] += m * O[(size_t)k * n + c];
+      }
+    for (int r = 0; r < n; ++r)
+      for (int c = 0; c < n; ++c) {
+        double acc = 0.0;
+        for (int i = 0; i < n; ++i) acc += O[(size_t)i * n + r] * Y[(size_t)i * n + c];
+        out[(size_t)r * n + c] = acc;
+      }
+  }
+};
+
+// how well the trace coordinate decouples: largest entry of row 0 / column 0 off what a decoupled block must hold
+struct DecoupleStat {
+  double worst = 0.0, scale = 0.0;
+  void see_block(const double* M, int n, bool identity_block) {     // M = O^T block O
+    for (int k = 0; k < n; ++k) {
+      const double want = (k == 0 && identity_block) ? 1.0 : 0.0;
+      worst = std::max(worst, std::fabs(M[k] - want));                       // row 0
+      worst = std::max(worst, std::fabs(M[(size_t)k * n] - want));           // column 0
+    }
+    for (int e = 0; e < n * n; ++e) scale = std::max(scale, std::fabs(M[e]));
+  }
+  bool ok() const { return worst <= 1e-12 * std::max(1.0, scale); }
+};
+
 }  // namespace
 
 struct m4q_session {
@@ -179,6 +235,7 @@ struct m4q_session {
   int grid = 1;
   DevBuf f[M4Q_F_COUNT];
   DevBuf Cq, Cqf, Cr, Wls, wsXg, wsUg, wsG, queue, head_done;
+  bool no_tile = false;
   size_t fbytes[M4Q_F_COUNT]{};
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // (start, stop) of launches not yet read by kernel_ms
   double folded_ms = 0.0;                                    // launches already completed and folded out of `pending`
@@ -190,13 +247,35 @@ struct m4q_session {
   // real path: inputs lifted to the Hermitian operator basis at upload time (doubles), and whether each was real there
   DevBuf r_models, r_x0, r_xtarg, r_Q, r_Qf, r_R;
   bool herm_ok[M4Q_F_COUNT] = {};
+  // traceless path: the same inputs on the n - 1 traceless coordinates, whether the trace coordinate decouples from each, and
+  // the range of trace coordinates seen in x0 / X_targ (state and target must share ONE trace for the cost to restrict)
+  DevBuf t_models, t_x0, t_xtarg, t_Q, t_Qf;
+  bool tl_ok[M4Q_F_COUNT] = {};
+  double tau_x0[2] = {0, 0}, tau_targ[2] = {0, 0};
+  bool no_traceless = false;
   bool force_complex = false;
   bool launched = false;        // a closed-loop launch has been enqueued since the watchdog flag was last read
   bool targ_const = false;      // every column of X_targ equals the first (per member, if per-member): xbar does not depend on t
-  bool use_real() const {
-    return !force_complex && ls_diag && herm_ok[M4Q_F_MODELS] && herm_ok[M4Q_F_X0] && herm_ok[M4Q_F_X_TARG] &&
+  bool use_real(bool diag) const {
+    return !force_complex && diag && herm_ok[M4Q_F_MODELS] && herm_ok[M4Q_F_X0] && herm_ok[M4Q_F_X_TARG] &&
            herm_ok[M4Q_F_Q] && herm_ok[M4Q_F_QF] && herm_ok[M4Q_F_R];
   }
+  bool use_real() const { return use_real(ls_diag); }
+  bool use_traceless(bool diag) const {
+    if (!use_real(diag) || no_traceless || !tl_ok[M4Q_F_MODELS] || !tl_ok[M4Q_F_X0] || !tl_ok[M4Q_F_X_TARG] || !tl_ok[M4Q_F_Q] ||
+        !tl_ok[M4Q_F_QF])
+      return false;
+    const double lo = std::min(tau_x0[0], tau_targ[0]), hi = std::max(tau_x0[1], tau_targ[1]);
+    return hi - lo <= 1e-12 * std::max(1.0, std::fabs(hi));
+  }
+  // 0 complex, 1 real (Hermitian basis), 2 real traceless.  diag: the line-search blocks of the costs are diagonal (known after
+  // the first run; m4q_session_path answers as if they were before that)
+  //                         3 traceless with the sweeps of the clipped solve on matrix-core tiles (constant targets only)
+  int path(bool diag) const {
+    if (!use_traceless(diag)) return use_real(diag) ? 1 : 0;
+    return (!no_tile && targ_const && !(prob.qp_flags & M4Q_QP_EXACT_BOX)) ? 3 : 2;
+  }
+  int path() const { return path(ls_diag); }
   std::vector<double> hQ, hQf, hR;
 };
 
@@ -260,6 +339,9 @@ int m4q_session_create(const m4q_problem* p, int32_t B, int32_t device, m4q_sess
   s->B = B;
   s->shape = sh;
   s->force_complex = (p->reserved & 1) != 0 || std::getenv("M4Q_FORCE_COMPLEX") != nullptr || sh->d * sh->d != p->dim_x;
+  // (M4Q_QP_REF_LQR builds its cost terms on xbar itself, lqr.py:54-58: the trace coordinate of the target does not drop out)
+  s->no_traceless = (p->reserved & M4Q_OPT_NO_TRACELESS) != 0 || std::getenv("M4Q_NO_TRACELESS") != nullptr ||
+                    (p->qp_flags & M4Q_QP_REF_LQR) != 0;
   if (sh->d * sh->d != p->dim_x && p->plant_kind != M4Q_PLANT_NONE) {
     delete s;
     return fail(M4Q_E_UNSUPPORTED, "dim_x=%d is not a vectorised density matrix: no device plant (use M4Q_PLANT_NONE)", p->dim_x);
@@ -296,6 +378,9 @@ int m4q_session_create(const m4q_problem* p, int32_t B, int32_t device, m4q_sess
   // the grid (and the per-row workspace) is sized for whichever path keeps more workgroups resident
   const int exact = (p->qp_flags & M4Q_QP_EXACT_BOX) ? 1 : 0;
   int per_cu = std::max(sh->occupancy(p->plant_kind, 0, exact), s->force_complex ? 0 : sh->occupancy(p->plant_kind, 1, exact));
+  s->no_tile = !((p->reserved & M4Q_OPT_TILE) != 0 || std::getenv("M4Q_TILE") != nullptr);     // experimental: opt-in
+  if (!s->force_complex && !s->no_traceless) per_cu = std::max(per_cu, sh->occupancy(p->plant_kind, 2, exact));
+  if (!s->force_complex && !s->no_traceless && !s->no_tile && !exact) per_cu = std::max(per_cu, sh->occupancy(p->plant_kind, 3, 0));
   if (per_cu < 1) per_cu = 1;
   if (const char* cap = std::getenv("M4Q_WGS_PER_CU")) {       // tuning experiments: fewer resident workgroups per CU
     const int v = std::atoi(cap);
@@ -308,7 +393,7 @@ int m4q_session_create(const m4q_problem* p, int32_t B, int32_t device, m4q_sess
   // [Xg rows][Xo rows] and [Ug rows][Uo rows]; the exact QP adds [Xalt rows] and [Ualt rows][working-set rows]
   if (!rc) rc = s->wsXg.alloc((exact ? 3 : 2) * rows * (T + 1) * n * C);
   if (!rc) rc = s->wsUg.alloc((exact ? 4 : 2) * rows * T * m * 8);
-  if (!rc) rc = s->queue.alloc(64);
+  if (!rc) rc = s->queue.alloc(192);       // 64 B of queue / watchdog / solver counters + 16 u64 phase clocks (dev builds)
   if (!rc) rc = s->head_done.alloc((size_t)B * 4);
   if (!rc) rc = s->wsG.alloc(rows * T * (n + 1) * m * C);
   if (!rc) rc = s->Cq.alloc(4 * n * n * 8);
@@ -384,6 +469,44 @@ static int lift_upload(m4q_session* s, int32_t field, const std::complex<double>
   int rc = dst.alloc(out.size() * sizeof(double));
   if (rc) return rc;
   HIP_TRY(hipMemcpy(dst.p, out.data(), out.size() * sizeof(double), hipMemcpyHostToDevice));
+  // ... and on the traceless coordinates
+  s->tl_ok[field] = false;
+  if (!s->herm_ok[field] || s->no_traceless) return 0;
+  const Traceless tl(s->shape->d);
+  const int ns = n - 1;
+  std::vector<double> tout, tmp((size_t)n * n);
+  DevBuf* tdst = field == M4Q_F_MODELS ? &s->t_models : field == M4Q_F_X0 ? &s->t_x0 : field == M4Q_F_X_TARG ? &s->t_xtarg :
+                 field == M4Q_F_Q ? &s->t_Q : &s->t_Qf;
+  if (!matrix) {
+    tout.resize(count_items * ns);
+    double lo = 0.0, hi = 0.0;
+    for (size_t it = 0; it < count_items; ++it) {
+      tl.vec(out.data() + it * n, tmp.data());
+      for (int i = 0; i < ns; ++i) tout[it * ns + i] = tmp[1 + i];
+      lo = it ? std::min(lo, tmp[0]) : tmp[0];
+      hi = it ? std::max(hi, tmp[0]) : tmp[0];
+    }
+    double* range = field == M4Q_F_X0 ? s->tau_x0 : s->tau_targ;
+    range[0] = lo; range[1] = hi;
+    s->tl_ok[field] = true;
+  } else {
+    const long ld = (long)n * nblk, lds = (long)ns * nblk;
+    tout.resize(count_items * ns * lds);
+    DecoupleStat dc;
+    for (size_t it = 0; it < count_items; ++it)
+      for (int p = 0; p < nblk; ++p) {
+        tl.mat(out.data() + it * n * ld + (long)p * n, ld, tmp.data());
+        // models: block 0 must carry the trace coordinate through unchanged, the N_p blocks must not touch it; costs: the cross
+        // terms with the (constant, shared) trace coordinate drop out of the objective's minimiser, nothing to check
+        if (field == M4Q_F_MODELS) dc.see_block(tmp.data(), n, p == 0);
+        for (int i = 0; i < ns; ++i)
+          for (int j = 0; j < ns; ++j) tout[it * ns * lds + i * lds + (long)p * ns + j] = tmp[(size_t)(1 + i) * n + 1 + j];
+      }
+    s->tl_ok[field] = field == M4Q_F_MODELS ? dc.ok() : true;
+  }
+  rc = tdst->alloc(tout.size() * sizeof(double));
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(tdst->p, tout.data(), tout.size() * sizeof(double), hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -430,9 +553,7 @@ int m4q_session_path(const m4q_session* s) {
   if (!s) return fail(M4Q_E_BADARG, "m4q_session_path: null session");
   // the line-search weights are derived from Q, Qf, R at the first run; before that, answer from the uploads alone
   const bool diag_known = !s->costs_dirty;
-  return (s->use_real() || (!diag_known && !s->force_complex && s->herm_ok[M4Q_F_MODELS] && s->herm_ok[M4Q_F_X0] &&
-                            s->herm_ok[M4Q_F_X_TARG] && s->herm_ok[M4Q_F_Q] && s->herm_ok[M4Q_F_QF] && s->herm_ok[M4Q_F_R]))
-             ? 1 : 0;
+  return s->path(diag_known ? s->ls_diag : true);
 }
 
 int m4q_session_download(m4q_session* s, int32_t field, void* host, size_t bytes) {
@@ -513,20 +634,24 @@ int m4q_session_run(m4q_session* s, int32_t step_begin, int32_t step_end) {
   const m4q_problem& p = s->prob;
   const size_t n = p.dim_x, m = p.dim_u, P = s->shape->np;
   const size_t k = p.plant_kind == M4Q_PLANT_GENERATOR ? n : (size_t)s->shape->d;
-  const bool real_path = s->use_real();
+  const int path = s->path();
+  const bool real_path = path != 0;
+  const size_t ns = path >= 2 ? n - 1 : n;         // dimension of the recursion
   m4q::MpcArgs a{};
   a.B = s->B; a.T = p.horizon; a.n_steps = p.n_steps; a.max_iter = p.max_iter; a.warm_start = p.warm_start;
   a.flags = p.qp_flags | (s->targ_const ? 256 : 0);      // 256 = QP_TARG_CONST (csrc/m4q_mpc.h), internal
   a.step_begin = step_begin; a.step_end = step_end;
   a.measure_freq = p.measure_freq > 1 ? p.measure_freq : 1;
   a.dt = p.dt; a.sat = p.sat; a.du = p.du; a.ls_tol = p.ls_tol;
-  a.models = real_path ? s->r_models.p : s->f[M4Q_F_MODELS].p; a.model_stride = p.model_per_instance ? (long)(n * n * (1 + P)) : 0;
+  a.models = path >= 2 ? s->t_models.p : real_path ? s->r_models.p : s->f[M4Q_F_MODELS].p;
+  a.model_stride = p.model_per_instance ? (long)(ns * ns * (1 + P)) : 0;
   a.x0c = (const cplx*)s->f[M4Q_F_X0].p;
-  a.x0s = real_path ? s->r_x0.p : s->f[M4Q_F_X0].p;
-  a.x_targ = real_path ? s->r_xtarg.p : s->f[M4Q_F_X_TARG].p; a.xt_stride = p.target_per_instance ? (long)(p.target_cols * n) : 0;
+  a.x0s = path >= 2 ? s->t_x0.p : real_path ? s->r_x0.p : s->f[M4Q_F_X0].p;
+  a.x_targ = path >= 2 ? s->t_xtarg.p : real_path ? s->r_xtarg.p : s->f[M4Q_F_X_TARG].p;
+  a.xt_stride = p.target_per_instance ? (long)(p.target_cols * ns) : 0;
   a.u_targ = (const double*)s->f[M4Q_F_U_TARG].p; a.ut_stride = p.target_per_instance ? (long)(p.target_cols * m) : 0;
-  a.Q = real_path ? s->r_Q.p : s->f[M4Q_F_Q].p;
-  a.Qf = real_path ? s->r_Qf.p : s->f[M4Q_F_QF].p;
+  a.Q = path >= 2 ? s->t_Q.p : real_path ? s->r_Q.p : s->f[M4Q_F_Q].p;
+  a.Qf = path >= 2 ? s->t_Qf.p : real_path ? s->r_Qf.p : s->f[M4Q_F_QF].p;
   a.R = real_path ? s->r_R.p : s->f[M4Q_F_R].p;
   a.Cq = (const double*)s->Cq.p; a.Cqf = (const double*)s->Cqf.p; a.Cr = (const double*)s->Cr.p;
   a.Wls = s->ls_diag ? (const double*)s->Wls.p : nullptr;
@@ -551,9 +676,9 @@ int m4q_session_run(m4q_session* s, int32_t step_begin, int32_t step_end) {
   if (s->launched) {
     // an earlier launch has not been synchronised yet: its watchdog flag (bytes 4..8) must survive until check_watchdog reads it
     HIP_TRY(hipMemsetAsync(s->queue.p, 0, 4, s->stream));
-    HIP_TRY(hipMemsetAsync((char*)s->queue.p + 8, 0, 56, s->stream));
+    HIP_TRY(hipMemsetAsync((char*)s->queue.p + 8, 0, 184, s->stream));
   } else {
-    HIP_TRY(hipMemsetAsync(s->queue.p, 0, 64, s->stream));
+    HIP_TRY(hipMemsetAsync(s->queue.p, 0, 192, s->stream));
   }
   HIP_TRY(hipMemsetAsync(s->head_done.p, 0, (size_t)s->B * 4, s->stream));
   if (step_begin == 0) {
@@ -576,7 +701,7 @@ int m4q_session_run(m4q_session* s, int32_t step_begin, int32_t step_end) {
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));
   HIP_TRY(hipEventRecord(e0, s->stream));
-  rc = s->shape->launch_mpc(a, p.plant_kind, real_path ? 1 : 0, s->grid, s->stream);
+  rc = s->shape->launch_mpc(a, p.plant_kind, path, s->grid, s->stream);
   if (rc) return fail(rc, "mpc kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));
   HIP_TRY(hipEventRecord(e1, s->stream));
   s->pending.emplace_back(e0, e1);
@@ -621,12 +746,22 @@ int m4q_session_kernel_ms(m4q_session* s, double* total_ms, int32_t* launches) {
 int m4q_session_qp_stats(m4q_session* s, int64_t* out6) {
   if (!s || !out6) return fail(M4Q_E_BADARG, "m4q_session_qp_stats: bad argument");
   HIP_TRY(hipStreamSynchronize(s->stream));
-  unsigned long long q[8];
+  unsigned long long q[24];
   HIP_TRY(hipMemcpy(q, s->queue.p, sizeof(q), hipMemcpyDeviceToHost));
   for (int i = 0; i < 6; ++i) out6[i] = (int64_t)q[1 + i];
   if (std::getenv("M4Q_QP_TRACE"))
     fprintf(stderr, "m4q: exact QP: %llu row sweeps in %llu wavefront passes (x4 rows = %llu): lane efficiency %.2f\n", q[2], q[7],
             4 * q[7], q[7] ? (double)q[2] / (4.0 * (double)q[7]) : 0.0);
+  if (std::getenv("M4Q_PHASE_TRACE")) {          // -DM4Q_DEV_PHASE_CLOCK builds: wavefront time per phase of the main loop, 100 MHz ticks
+    static const char* names[16] = {"draw/resume", "backward | exact: adjoint pass", "forward", "handover", "line search", "step done (plant, shift)", "publish",
+                                    "passes", "guess update", "passes with a line search", "exact: pinned sweep", "exact: policy rollout",
+                                    "exact: ratio rollout", "exact: blend", "exact: open rollout", "exact: bookkeeping + copies"};
+    unsigned long long tot = 0;
+    for (int i = 0; i < 16; ++i) tot += (i == 7 || i == 9) ? 0 : q[8 + i];
+    for (int i = 0; i < 16; ++i)
+      fprintf(stderr, "m4q phase %-30s %14llu %s  %5.1f %%\n", names[i], q[8 + i], (i == 7 || i == 9) ? "     " : "ticks",
+              (i != 7 && i != 9 && tot) ? 100.0 * (double)q[8 + i] / (double)tot : 0.0);
+  }
   return check_watchdog(s);
 }
 
@@ -637,7 +772,7 @@ int m4q_session_info(const m4q_session* s, int64_t* hbm_bytes, int32_t* grid, in
   tot += (int64_t)(s->wsXg.bytes + s->wsUg.bytes + s->wsG.bytes);
   if (hbm_bytes) *hbm_bytes = tot;
   if (grid) *grid = s->grid;
-  if (lds_bytes) *lds_bytes = (int32_t)s->shape->mpc_lds_bytes(s->use_real() ? 1 : 0);
+  if (lds_bytes) *lds_bytes = (int32_t)s->shape->mpc_lds_bytes(s->path());
   return 0;
 }
 
@@ -830,6 +965,7 @@ int m4q_session_build_models(m4q_session* s, double dt, const double* generators
       hb.lift_mat(g + q * n * n, (long)n, tmp.data(), (long)n);
       for (size_t e = 0; e < n * n; ++e) { st.see(tmp[e]); lifted[q * n * n + e] = tmp[e].real(); }
     }
+    s->tl_ok[M4Q_F_MODELS] = false;
     if (st.real_enough()) {
       void* d_gr;
       if ((rc = t.up(lifted.data(), lifted.size() * 8, &d_gr))) return rc;
@@ -839,6 +975,31 @@ int m4q_session_build_models(m4q_session* s, double dt, const double* generators
       rc = s->shape->launch_discretize(r, 1, s->stream);
       if (rc) return fail(rc, "discretize launch failed");
       s->herm_ok[M4Q_F_MODELS] = true;
+      if (!s->no_traceless) {
+        // ... and on the traceless coordinates: generators that leave the trace coordinate alone (row 0 and column 0 of O^T G O
+        // zero: trace-preserving and unital, every -i[H, .] is) have block-diagonal products, so the expansion of their
+        // (n-1) x (n-1) blocks IS the traceless block of the model
+        const Traceless tl(s->shape->d);
+        const size_t m1 = n - 1;
+        std::vector<double> blocks(nset * (1 + m) * m1 * m1), rot(n * n);
+        DecoupleStat dc;
+        for (size_t q = 0; q < nset * (1 + m); ++q) {
+          tl.mat(lifted.data() + q * n * n, (long)n, rot.data());
+          dc.see_block(rot.data(), (int)n, false);
+          for (size_t i = 0; i < m1; ++i)
+            for (size_t j2 = 0; j2 < m1; ++j2) blocks[q * m1 * m1 + i * m1 + j2] = rot[(1 + i) * n + 1 + j2];
+        }
+        if (dc.ok()) {
+          void* d_gt;
+          if ((rc = t.up(blocks.data(), blocks.size() * 8, &d_gt))) return rc;
+          if ((rc = s->t_models.alloc(nmodels * m1 * m1 * (1 + P) * 8))) return rc;
+          m4q::DiscArgs q2 = a;
+          q2.gens = d_gt; q2.gen_stride = gen_per_instance ? (long)((1 + m) * m1 * m1) : 0; q2.models = s->t_models.p;
+          rc = s->shape->launch_discretize(q2, 2, s->stream);
+          if (rc) return fail(rc, "discretize launch failed");
+          s->tl_ok[M4Q_F_MODELS] = true;
+        }
+      }
     }
   }
   HIP_TRY(hipStreamSynchronize(s->stream));

@@ -17,6 +17,15 @@
 #include <type_traits>
 #include <utility>
 
+// Development-only switches - a debug form of the row broadcast (ds_bpermute instead of DPP), an override of the DPP wait-state
+// pad, the per-phase clock, the two-index complex sweep - exist only in builds that say so: build.py passes -DM4Q_DEV for
+// `--dev` alone and tools/build_variant.sh (whose libraries never ship) always.  The timing-only ablation paths of round 2
+// ("results wrong": M4Q_EXP) are gone from the sources; what they measured is in profiles/r02_ab_experiments.txt.
+#if !defined(M4Q_DEV) && (defined(M4Q_BCAST_SHFL) || defined(M4Q_NOP) || defined(M4Q_DEV_PHASE_CLOCK) || defined(M4Q_TWO_INDEX_COMPLEX) || \
+                          defined(M4Q_EXP))
+#error "development switch without -DM4Q_DEV: use build.py --dev or tools/build_variant.sh"
+#endif
+
 namespace m4q {
 
 struct cplx {
@@ -132,6 +141,24 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+
+// ---- development builds (-DM4Q_DEV_PHASE_CLOCK): wavefront time per phase of the persistent loop, summed on the constant
+// 100 MHz clock; an empty object otherwise.  Slots: see m4q_session_qp_stats (M4Q_PHASE_TRACE=1 prints them).
+struct PhaseClock {
+#if defined(M4Q_DEV_PHASE_CLOCK)
+  unsigned long long acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t = __builtin_amdgcn_s_memrealtime();
+  __device__ __forceinline__ void mark(int i) {
+    const unsigned long long n = __builtin_amdgcn_s_memrealtime();
+    acc[i] += n - t;
+    t = n;
+  }
+  __device__ __forceinline__ void count(int i) { ++acc[i]; }
+#else
+  __device__ __forceinline__ void mark(int) {}
+  __device__ __forceinline__ void count(int) {}
+#endif
+};
 
 // ---- compile-time loop with an integral_constant index (DPP controls are immediates) ----
 template <int I>

@@ -6,6 +6,7 @@
 #define M4Q_KERNEL_TU 1
 #include "m4q_args.h"
 #include "m4q_mpc.h"
+#include "m4q_tile.h"
 
 #ifndef M4Q_NX
 #error "compile with -DM4Q_NX -DM4Q_NU -DM4Q_ORDER"
@@ -28,6 +29,7 @@ constexpr bool SQUARE = DD * DD == NX;
 constexpr int NP = PowTab<NU, ORDER>::NP;
 constexpr int PITCH = ModelPitch<NX>::value;
 constexpr int MODEL_ELEMS = (1 + NP) * NX * PITCH;        // per instance, elements (of S) in LDS
+// the traceless path (m4q_mpc.h) runs the recursion on NX - 1 coordinates; everything it stages is no larger than the above
 constexpr int SCRATCH_ELEMS = (SQUARE ? DD * DD : 0) + 2 * NX;   // plant / basis-change scratch per instance (complex)
 constexpr int ROWS = 4;                                    // instances per wavefront
 
@@ -45,17 +47,17 @@ template <> struct WavesFor<double> { static constexpr int value = M4Q_WAVES_REA
 extern __shared__ __align__(16) unsigned char m4q_lds_raw[];
 
 // copy one instance's model (DMDc.A layout, n x n(1+P) row-major) into its LDS block [1+P][n][PITCH]
-template <class S>
+template <int N, class S>
 __device__ __forceinline__ void stage_model(S* dst, const M4Q_GLOBAL S* src, int jj) {
-  constexpr int W = NX * (1 + NP);
+  constexpr int W = N * (1 + NP);
   // (not unrolled: unrolling this loop costs registers and time, profiles/r02_ab_experiments.txt)
 #pragma unroll 1
-  for (int e = jj; e < NX * W; e += 16) {
+  for (int e = jj; e < N * W; e += 16) {
     const int i = e / W;
     const int pk = e - i * W;
-    const int p = pk / NX;
-    const int k = pk - p * NX;
-    dst[ModelPitch<NX>::at(p, i, k)] = gld(src, e);
+    const int p = pk / N;
+    const int k = pk - p * N;
+    dst[ModelPitch<N>::at(p, i, k)] = gld(src, e);
   }
 }
 
@@ -97,13 +99,20 @@ constexpr int WLS_DOUBLES = 4 * NX + 2 * NU;               // diagonal line-sear
 constexpr int STASH_INTS = 12;                             // per-row words of RowStash
 constexpr int STASH_BYTES = 8 /* watchdog deadline */ + ROWS * STASH_INTS * 4 + 64 * 16 /* x_meas, one S per lane */;
 
-template <class S>
+// sizes of the staged model and costs for a recursion on N coordinates
+template <int N> constexpr int model_elems() { return (1 + NP) * N * ModelPitch<N>::value; }
+template <int N> constexpr int cost_elems() { return 2 * N * N + NU * NU; }
+
+template <class S, bool TL = false, bool TILE = false>
 constexpr size_t mpc_lds_layout_bytes() {
-  return sizeof(S) * (size_t)(ROWS * MODEL_ELEMS + COST_ELEMS) + sizeof(cplx) * (size_t)(ROWS * SCRATCH_ELEMS) +
-         sizeof(double) * (size_t)WLS_DOUBLES + (size_t)STASH_BYTES;
+  constexpr int N = TL ? NX - 1 : NX;
+  return sizeof(S) * (size_t)(ROWS * model_elems<N>() + cost_elems<N>()) + sizeof(cplx) * (size_t)(ROWS * SCRATCH_ELEMS) +
+         sizeof(double) * (size_t)WLS_DOUBLES + (size_t)STASH_BYTES + (TILE ? (size_t)TILE_LDS_BYTES : 0);
 }
 
 __device__ __forceinline__ int row_bcast_int(int v) { return __shfl(v, 0, 16); }
+// the same wave-uniform number, opaque to the compiler: what is derived from it is computed (and dies) where it is used
+__device__ __forceinline__ int fresh(int v) { asm volatile("" : "+s"(v)); return v; }
 
 // Kernel arguments are read out of the kernarg segment WHERE THEY ARE USED.  Taken as a by-value parameter the 46 fields of
 // MpcArgs are loaded at kernel entry, stay live for the whole persistent loop and - the kernel has 106 scalar registers -
@@ -134,22 +143,51 @@ struct RowStash {
   __device__ __forceinline__ void get_x(cplx& v) const { v.re = xm[2 * threadIdx.x]; v.im = xm[2 * threadIdx.x + 1]; }
 };
 
-template <class S, int PLANT, bool EXACT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>::value, 8))) void mpc_kernel(MpcArgs) {
+// TL: the state lives in the NX - 1 traceless coordinates (S = double only; m4q_mpc.h).  NS = dimension of the recursion;
+// the I/O side (xs, the SQP-guess checkpoint, the plant) stays NX complex numbers per node.
+// TILE: the two sweeps of the clipped solve run on fp64 matrix-core tiles (m4q_tile.h) instead of DPP rows.
+#ifndef M4Q_WAVES_TILE
+#define M4Q_WAVES_TILE 2
+#endif
+#ifndef M4Q_TILE_FORWARD
+#define M4Q_TILE_FORWARD 0      // the tile variant runs its BACKWARD sweep on matrix-core tiles and the rollout on DPP rows (1: both on tiles)
+#endif
+// Development builds (-DM4Q_DEV_PHASE_CLOCK): PhaseClock (m4q_device.h) sums the 100 MHz clock over the phases of the main loop; every
+// wavefront adds its sums to queue[8..23] (u64) on exit; M4Q_PHASE_TRACE=1 makes m4q_session_qp_stats print them.
+#if defined(M4Q_DEV_PHASE_CLOCK)
+#define M4Q_PHASE_FLUSH() if (threadIdx.x == 0) { for (int i = 0; i < 16; ++i) __hip_atomic_fetch_add((M4Q_GLOBAL unsigned long long*)kargs()->queue + 8 + i, pc.acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#else
+#define M4Q_PHASE_FLUSH()
+#endif
+#define M4Q_PHASE_DECL PhaseClock pc;
+#define M4Q_PHASE_MARK(i) pc.mark(i);
+template <class S, int PLANT, bool EXACT, bool TL = false, bool TILE = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_WAVES_TILE : WavesFor<S>::value, 8))) void mpc_kernel(MpcArgs) {
+  static_assert(!TL || (sizeof(S) == sizeof(double) && SQUARE), "the traceless path is a real path of a d x d density matrix");
+  static_assert(!TILE || (TL && !EXACT), "tile sweeps: clipped solve on the traceless real coordinates");
+  constexpr int NS = TL ? NX - 1 : NX;
   // LDS: [4 x scratch (complex)] [4 x model (S)] [Q Qf R (S)] [line-search weights] [watchdog deadline, row stash]
   cplx* scratch = reinterpret_cast<cplx*>(m4q_lds_raw);
   S* lds = reinterpret_cast<S*>(scratch + ROWS * SCRATCH_ELEMS);
   const LaneGeo L;
-  const int g = L.g, jj = L.jj, j = L.j;
-  const bool lane_ok = L.lane_ok;
-  S* mdl = lds + g * MODEL_ELEMS;
+  const int g = L.g, jj = L.jj;
+  const int j = jj < NS ? jj : NS - 1;           // this lane's state coordinate (lanes that own none shadow the last)
+  const int jio = L.j;                           // ... and its slot of vec(rho) on the I/O side
+  const bool lane_ok = jj < NS, lane_io = L.lane_ok;
+  double tau = 0.0;                              // TL: the member's trace coordinate tr(rho)/sqrt(d) (row-uniform)
+  constexpr int MODEL_K = model_elems<NS>(), COST_K = cost_elems<NS>();
+  S* mdl = lds + g * MODEL_K;
   scratch += g * SCRATCH_ELEMS;
-  S* ldsQ = lds + ROWS * MODEL_ELEMS;
-  double* ldsW = reinterpret_cast<double*>(ldsQ + COST_ELEMS);
+  S* ldsQ = lds + ROWS * MODEL_K;
+  double* ldsW = reinterpret_cast<double*>(ldsQ + COST_K);
   volatile M4Q_LDS unsigned long long* wd_slot = (volatile M4Q_LDS unsigned long long*)(ldsW + WLS_DOUBLES);
   RowStash<S> stash;
   stash.w = (volatile M4Q_LDS int*)(ldsW + WLS_DOUBLES + 1);
   stash.xm = (volatile M4Q_LDS double*)(stash.w + ROWS * STASH_INTS);
+  // TILE: hand-over block between the DPP-row state machine and the tile sweeps, and the G / h broadcast tiles
+  volatile M4Q_LDS double* tio = stash.xm + 64 * 2;
+  volatile M4Q_LDS int* tiw = (volatile M4Q_LDS int*)(tio + ROWS * TILE_IO_DOUBLES);
+  volatile M4Q_LDS double* tgb = (volatile M4Q_LDS double*)(tiw + ROWS * TILE_IO_WORDS);
   int T0, flags;
   bool ls_diag, two_phase;
   {
@@ -159,8 +197,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
     const M4Q_GLOBAL S* gQ = (const M4Q_GLOBAL S*)a->Q;
     const M4Q_GLOBAL S* gQf = (const M4Q_GLOBAL S*)a->Qf;
     const M4Q_GLOBAL S* gR = (const M4Q_GLOBAL S*)a->R;
-    for (int e = threadIdx.x; e < COST_ELEMS; e += 64)
-      ldsQ[e] = e < NX * NX ? gld(gQ, e) : (e < 2 * NX * NX ? gld(gQf, e - NX * NX) : gld(gR, e - 2 * NX * NX));
+    for (int e = threadIdx.x; e < 2 * NS * NS + NU * NU; e += 64)
+      ldsQ[e] = e < NS * NS ? gld(gQ, e) : (e < 2 * NS * NS ? gld(gQf, e - NS * NS) : gld(gR, e - 2 * NS * NS));
     ls_diag = a->Wls != nullptr;
     if (ls_diag) {
       for (int e = threadIdx.x; e < WLS_DOUBLES; e += 64) ldsW[e] = gld(a->Wls, e);
@@ -177,15 +215,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
     if (threadIdx.x == 0) *wd_slot = __builtin_amdgcn_s_memrealtime() + a->deadline_ticks;
   }
   CostRef<S> cost;
-  cost.Q = ldsQ; cost.Qf = ldsQ + NX * NX; cost.q_stride = 0; cost.R = ldsQ + 2 * NX * NX; cost.r_stride = 0;
+  cost.Q = ldsQ; cost.Qf = ldsQ + NS * NS; cost.q_stride = 0; cost.R = ldsQ + 2 * NS * NS; cost.r_stride = 0;
   // workspace of this resident row: wave-uniform base per workgroup, lane part = row within the wave
-  const unsigned sX = (unsigned)(T0 + 1) * NX, sU = (unsigned)T0 * NU, sG = (unsigned)T0 * (NX + 1) * NU;
+  const unsigned sX = (unsigned)(T0 + 1) * NS, sU = (unsigned)T0 * NU, sG = (unsigned)T0 * (NS + 1) * NU;
+  const unsigned sXc = (unsigned)(T0 + 1) * NX;            // the SQP-guess checkpoint field: complex, NX per node
   // Lanes NX..15 of a row own no column (7 of 16 at d = 3, 12 of 16 at d = 2).  Left enabled they run the sweeps on a copy of
   // column NX-1's data: harmless for the results, but the fp64 pipe spends power on them, and the clock this chip holds under an
   // fp64-dense load follows the power.  EXEC is therefore off for them during the two sweeps (every DPP source is a lane < NX;
   // results bit-identical): the complex path runs at 2.30 GHz instead of 2.04 (133.3 -> 117.6 ms, config 3), the real path at 2.29
   // instead of 2.18 (51.2 -> 50.4 ms; config 5's share 171.2 -> 166.3 ms).  profiles/r02_ab_experiments.txt, r02_clock_ramp.txt.
-  constexpr bool MASK_IDLE = M4Q_MASK_IDLE && NX < 16 && !EXACT;
+  constexpr bool MASK_IDLE = M4Q_MASK_IDLE && NS < 16 && !EXACT && !TILE;
   GView Xg, Ug, Xo, Uo, gains, Xalt, Ualt, pin_stat;
   {
     KArgs* a = kargs();
@@ -220,6 +259,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
   int qp_passes = 0;           // passes of this wavefront through the solver iteration (statistics)
   unsigned xt_off = 0, ut_off = 0, op0_off = 0, ops_off = 0;      // this row's member inside the per-member arrays (bytes)
   wave_sync();
+  M4Q_PHASE_DECL
 
   while (true) {
     // The horizon and the row's workspace offsets go through an opaque asm once per pass: everything derived from them
@@ -230,12 +270,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
     asm volatile("" : "+s"(T));
     asm volatile("" : "+v"(Xg.off), "+v"(Ug.off), "+v"(Xo.off), "+v"(Uo.off), "+v"(gains.off));
     if constexpr (EXACT) asm volatile("" : "+v"(Xalt.off), "+v"(Ualt.off), "+v"(pin_stat.off));
-    FusedProv<S, NX, NU, ORDER> prov;
+    FusedProv<S, NS, NU, ORDER> prov;
     prov.mdl = mdl; prov.Xg = Xg; prov.Ug = Ug; prov.j = j;
     if (__builtin_amdgcn_s_memrealtime() > *wd_slot) {
       if (threadIdx.x == 0) __hip_atomic_store(kargs()->queue + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       break;
     }
+    M4Q_PHASE_MARK(3)
     // ---- rows without work draw the next item; tail items wait (without blocking) for their head ----
     if (__any(need_new || pending)) {
       KArgs* a = kargs();
@@ -268,7 +309,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
       if (fresh) { pending = false; active = true; }
       wave_sync();
       if (fresh) {
-        stage_model(mdl, (const M4Q_GLOBAL S*)a->models + b * a->model_stride, jj);
+        stage_model<NS>(mdl, (const M4Q_GLOBAL S*)a->models + b * a->model_stride, jj);
         xt_off = (unsigned)(b * a->xt_stride) * (unsigned)sizeof(S);
         ut_off = (unsigned)(b * a->ut_stride) * (unsigned)sizeof(double);
         op0_off = (unsigned)(b * a->op0_stride) * (unsigned)sizeof(cplx);
@@ -281,34 +322,50 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
       if (__any(fresh && row_begin == 0)) {
         if (fresh && row_begin == 0) {
           // X_guess = tile(x0), U_guess = 0 (mpc.py:141-142); xs[0] = x0 (:160)
-          const S x0 = gld((const M4Q_GLOBAL S*)a->x0s, b * NX + j);
+          const S x0 = gld((const M4Q_GLOBAL S*)a->x0s, b * NS + j);
           x_cur = x0;
           x_meas = x0;
           if (lane_ok) {
 #pragma unroll 8
-            for (int t = 0; t <= T; ++t) Xg.st<S>(t * NX + j, x0);
-            gst(a->xs, b * sXs + j, gld(a->x0c, b * NX + j));
+            for (int t = 0; t <= T; ++t) Xg.st<S>(t * NS + j, x0);
           }
+          if (lane_io) gst(a->xs, b * sXs + jio, gld(a->x0c, b * NX + jio));
           for (int e = jj; e < T * NU; e += 16) Ug.st<double>(e, 0.0);
+        }
+        if constexpr (TL) {
+          // the member's trace coordinate, from the complex x0 (every lane of the row ends up with it)
+          double t0 = 0.0;
+          const cplx xc = (fresh && row_begin == 0) ? gld(a->x0c, b * NX + jio) : czero();
+          (void)Basis<S, TL>::template to_state<NX, DD>(xc, scratch, j, jj, t0);
+          if (fresh && row_begin == 0) tau = t0;
         }
       }
       if (__any(fresh && row_begin != 0)) {
         // resume: the SQP guess, state and exit code of an earlier item or launch (fields X_GUESS/U_GUESS/XS/US/CODES).
         // The stored guess is complex in the original basis; the basis change needs every lane (LDS exchange).
         const bool rs = fresh && row_begin != 0;
-#pragma unroll 4
-        for (int t = 0; t <= T; ++t) {
-          const cplx xc = rs ? gld(a->Xg, b * sX + t * NX + j) : czero();
-          const S r = BasisIO<S>::template to_state<NX, DD>(xc, scratch, j, jj);
-          if (rs && lane_ok) Xg.st<S>(t * NX + j, r);
+        double tdum = 0.0, tnew = 0.0;
+        for (int t0 = 0; t0 <= T; t0 += 8) {
+          cplx v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = rs ? gld(a->Xg, b * sXc + (t0 + q <= T ? t0 + q : T) * NX + jio) : czero();
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            if (t0 + q <= T) {
+              const S r = Basis<S, TL>::template to_state<NX, DD>(v[q], scratch, j, jj, tdum);
+              if (rs && lane_ok) Xg.st<S>((t0 + q) * NS + j, r);
+            }
+          }
         }
-        const cplx xc = rs ? gld(a->xs, b * sXs + (long)row_begin * NX + j) : czero();
-        const S r = BasisIO<S>::template to_state<NX, DD>(xc, scratch, j, jj);
-        const cplx xm = rs ? gld(a->xs, b * sXs + (long)(row_begin / mf) * mf * NX + j) : czero();
-        const S rm = BasisIO<S>::template to_state<NX, DD>(xm, scratch, j, jj);
+        const cplx xc = rs ? gld(a->xs, b * sXs + (long)row_begin * NX + jio) : czero();
+        const S r = Basis<S, TL>::template to_state<NX, DD>(xc, scratch, j, jj, tdum);
+        const cplx xm = rs ? gld(a->xs, b * sXs + (long)(row_begin / mf) * mf * NX + jio) : czero();
+        const S rm = Basis<S, TL>::template to_state<NX, DD>(xm, scratch, j, jj, tnew);
         if (rs) {
           x_cur = r;
           x_meas = rm;
+          tau = tnew;
           for (int e = jj; e < T * NU; e += 16) Ug.st<double>(e, gld(a->Ug, b * sU + e));
           code = gld(a->codes, b);
           done_steps = gld(a->steps_done, b);
@@ -319,7 +376,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
       }
       wave_sync();
     }
+    M4Q_PHASE_MARK(0)
     if (!__any(active || pending)) {
+      M4Q_PHASE_FLUSH()
       if (EXACT && threadIdx.x == 0)
         __hip_atomic_fetch_add((M4Q_GLOBAL unsigned long long*)kargs()->queue + 7, (unsigned long long)qp_passes, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
@@ -357,7 +416,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
       // target window: X_ref = X_targ[:, :T+1] for steps 0 and 1, then X_targ[:, step-1:...] (mpc.py:145,276)
       const int w = step <= 1 ? 0 : step - 1;
       win.xbm = gview((const M4Q_GLOBAL S*)a->x_targ, 0, 0);
-      win.xbm.off = xt_off + (unsigned)w * NX * (unsigned)sizeof(S);
+      win.xbm.off = xt_off + (unsigned)w * NS * (unsigned)sizeof(S);
       win.ubm = gview(a->u_targ, 0, 0);
       win.ubm.off = ut_off + (unsigned)w * NU * (unsigned)sizeof(double);
       const double sat = a->sat, du = a->du;
@@ -371,20 +430,91 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
       }
       use_ls = !(a->warm_start && step > 1);        // mpc.py:208-213
       const bool st = running && lane_ok;
-      if constexpr (!EXACT) {
+      if constexpr (TILE) {
+        // ---- hand the row's solve to the tile layout: member = (lane >> 2) & 3 there, lane >> 4 here ----
+        if (lane_ok) tio[g * TILE_IO_DOUBLES + jj] = real_of(x_cur);
+        if (jj == 0) {
+#pragma unroll
+          for (int k = 0; k < NU; ++k) { tio[g * TILE_IO_DOUBLES + 16 + k] = lo0[k]; tio[g * TILE_IO_DOUBLES + 19 + k] = hi0[k]; }
+          tiw[g * TILE_IO_WORDS + 0] = (running ? 1 : 0) | (use_ls ? 0 : 2);
+          tiw[g * TILE_IO_WORDS + 1] = (int)win.xbm.off;
+          tiw[g * TILE_IO_WORDS + 2] = (int)win.ubm.off;
+        }
+        wave_sync();
+        {
+          TileSweeps<NS, NU, ORDER> ts;
+          const int mb = ts.L.mb;
+          const int dm = mb - g;                                 // this lane's member there minus its member here
+          ts.mdl = reinterpret_cast<const double*>(lds) + mb * MODEL_K;
+          ts.T = T;
+          ts.Xg = Xg; ts.Xg.off = Xg.off + (unsigned)(dm * (int)(sX * sizeof(double)));
+          ts.Ug = Ug; ts.Ug.off = Ug.off + (unsigned)(dm * (int)(sU * sizeof(double)));
+          ts.gains = gains; ts.gains.off = gains.off + (unsigned)(dm * (int)(sG * sizeof(double)));
+          const int tfl = tiw[mb * TILE_IO_WORDS + 0];
+          ts.xbm = win.xbm; ts.xbm.off = (unsigned)tiw[mb * TILE_IO_WORDS + 1];
+          ts.ubm = win.ubm; ts.ubm.off = (unsigned)tiw[mb * TILE_IO_WORDS + 2];
+          ts.Q = reinterpret_cast<const double*>(cost.Q); ts.Qf = reinterpret_cast<const double*>(cost.Qf);
+          ts.R = reinterpret_cast<const double*>(cost.R);
+          ts.gb = tgb + mb * TILE_GB_DOUBLES;
+          const bool run_t = (tfl & 1) != 0, shift_t = (tfl & 2) != 0;
+          M4Q_PHASE_MARK(3)
+          ts.backward(run_t);
+          wave_sync();
+          M4Q_PHASE_MARK(1)
+#if M4Q_TILE_FORWARD
+          double x0t[TileSweeps<NS, NU, ORDER>::NT], lo_t[NU], hi_t[NU], uf[NU];
+#pragma unroll
+          for (int K = 0; K < TileSweeps<NS, NU, ORDER>::NT; ++K) {
+            const int e = 4 * K + ts.L.r;
+            const double v = tio[mb * TILE_IO_DOUBLES + (e < NS ? e : 0)];
+            x0t[K] = e < NS ? v : 0.0;
+          }
+#pragma unroll
+          for (int k = 0; k < NU; ++k) {
+            lo_t[k] = tio[mb * TILE_IO_DOUBLES + 16 + k];
+            hi_t[k] = tio[mb * TILE_IO_DOUBLES + 19 + k];
+            uf[k] = 0.0;
+          }
+          GView Xd = Xo, Ud = Uo;
+          Xd.off = (shift_t ? Xg.off : Xo.off) + (unsigned)(dm * (int)(sX * sizeof(double)));
+          Ud.off = (shift_t ? Ug.off : Uo.off) + (unsigned)(dm * (int)(sU * sizeof(double)));
+          const double ck = ts.forward(x0t, sat, lo_t, hi_t, Xd, Ud, shift_t, run_t, uf);
+          M4Q_PHASE_MARK(2)
+          if (ts.L.r == 0 && ts.L.q == 0) {
+#pragma unroll
+            for (int k = 0; k < NU; ++k) tio[mb * TILE_IO_DOUBLES + 22 + k] = uf[k];
+            tio[mb * TILE_IO_DOUBLES + 25] = ck;
+          }
+#endif
+        }
+        wave_sync();
+#if M4Q_TILE_FORWARD
+#pragma unroll
+        for (int k = 0; k < NU; ++k) uapp[k] = tio[g * TILE_IO_DOUBLES + 22 + k];
+        chk = tio[g * TILE_IO_DOUBLES + 25];
+        wave_sync();
+#else
+        // the rollout on DPP rows: one short dependent chain per index, where the tile form waits on every operand
+        // (profiles/r03_phase_clock.txt: 3,060 cycles per index against 1,320)
+        chk = rollout_forward<S, NS, NU, false>(prov, T, x_cur, win, cost, flags, gains, sat, lo0, hi0, Xo, Uo, j, st, uapp, !use_ls, &Xg, &Ug);
+#endif
+      } else if constexpr (!EXACT) {
         // (xbar_t the same for every t: the sweep needs no row form of A_t - wave-uniform choice between two instantiations.
         //  n = 16 real path only: config 4 85.5 -> 84.2 ms; at n = 9 the kernel with both instantiations is SLOWER, 50.65 -> 51.7 ms,
         //  although it executes 27 vector instructions fewer per horizon index - profiles/r02_ab_experiments.txt)
-        constexpr bool HAS_TC = M4Q_TARG_CONST && NX == 16 && sizeof(S) == sizeof(double);
+        constexpr bool HAS_TC = M4Q_TARG_CONST && NS >= 15 && sizeof(S) == sizeof(double);
         bool tc = false;
         if constexpr (HAS_TC) tc = (flags & QP_TARG_CONST) != 0;
         if constexpr (HAS_TC) {
-          if (tc) riccati_backward<S, NX, NU, FusedProv<S, NX, NU, ORDER>, false, true>(prov, T, win, cost, flags, gains, j, st);
+          if (tc && (!MASK_IDLE || lane_ok))
+            riccati_backward<S, NS, NU, FusedProv<S, NS, NU, ORDER>, false, true>(prov, T, win, cost, flags, gains, j, st);
         }
-        if (!tc && (!MASK_IDLE || lane_ok)) riccati_backward<S, NX, NU>(prov, T, win, cost, flags, gains, j, st);
+        M4Q_PHASE_MARK(3)
+        if (!tc && (!MASK_IDLE || lane_ok)) riccati_backward<S, NS, NU>(prov, T, win, cost, flags, gains, j, st);
         wave_sync();
+        M4Q_PHASE_MARK(1)
         if (!MASK_IDLE || lane_ok)
-          chk = rollout_forward<S, NX, NU, false>(prov, T, x_cur, win, cost, flags, gains, sat, lo0, hi0, Xo, Uo, j, st, uapp,
+          chk = rollout_forward<S, NS, NU, false>(prov, T, x_cur, win, cost, flags, gains, sat, lo0, hi0, Xo, Uo, j, st, uapp,
                                                   !use_ls, &Xg, &Ug);
         if constexpr (MASK_IDLE) {
           // the row's scalars back into the lanes that sat the sweep out
@@ -403,17 +533,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
         // (Xg, Ug) stays untouched until the solve is over.
         const bool start = running && !qp.busy;
         double J0 = 0.0;
+        M4Q_PHASE_MARK(3)
         if (__any(start)) {
-          J0 = rollout_open<S, NX, NU>(prov, T, x_cur, win, cost, Ug, pin.box, lo0, hi0, Xo, Uo, j, start && lane_ok);
+          J0 = rollout_open<S, NS, NU>(prov, fresh(T), x_cur, win, cost, Ug, pin.box, lo0, hi0, Xo, Uo, j, start && lane_ok);
           wave_sync();
         }
+        M4Q_PHASE_MARK(14)
         bool bad_start = false;
         if (start) {
           qp.begin(J0);
           if (!finite_d(J0)) { qp.busy = false; bad_start = true; }
         }
         if (__any(qp.busy)) ++qp_passes;
-        const bool ended = box_qp_iterate<S, NX, NU>(prov, T, x_cur, win, cost, flags, gains, pin, Xo, Uo, Xalt, Ualt, qp, j, jj, lane_ok);
+        const bool ended = box_qp_iterate<S, NS, NU>(prov, fresh(T), x_cur, win, cost, flags, gains, pin, Xo, Uo, Xalt, Ualt, qp, j, jj, lane_ok, &pc);
         solved = running && (ended || bad_start);
         capped = solved && !bad_start && qp.stats.end_cap > 0;
         chk = qp.Jk;
@@ -432,29 +564,57 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
         if (solved && !bad_start) {
 #pragma unroll
           for (int k = 0; k < NU; ++k) uapp[k] = Us.ld<double>(k);
-          if (use_ls) {
-            // (these copies are latency bound: unrolled so that several loads are in flight)
-            if (!qp.cur_is_a) {
-              if (lane_ok) {
-#pragma unroll 8
-                for (int t = 0; t <= T; ++t) Xo.st<S>(t * NX + j, Xs.ld<S>(t * NX + j));
+          // (the row's 16 lanes share the contiguous elements; a batch issues all its loads before the first store)
+          auto copy_x = [&](const GView& dst, const GView& src, int shift) __attribute__((always_inline)) {
+            constexpr int U = 12;
+            const int count = (T + 1) * NS, last = T * NS;
+            for (int e0 = jj; e0 < count; e0 += 16 * U) {
+              S v[U];
+#pragma unroll
+              for (int u = 0; u < U; ++u) {
+                const int e = e0 + 16 * u < count ? e0 + 16 * u : count - 1;
+                v[u] = src.ld<S>(e < last ? e + shift : e);
               }
-#pragma unroll 4
-              for (int e = jj; e < T * NU; e += 16) Uo.st<double>(e, Us.ld<double>(e));
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int u = 0; u < U; ++u)
+                if (e0 + 16 * u < count) dst.st<S>(e0 + 16 * u, v[u]);
+            }
+          };
+          auto copy_u = [&](const GView& dst, const GView& src, int shift) __attribute__((always_inline)) {
+            constexpr int U = 8;
+            const int count = T * NU, last = (T - 1) * NU;
+            for (int e0 = jj; e0 < count; e0 += 16 * U) {
+              double v[U];
+#pragma unroll
+              for (int u = 0; u < U; ++u) {
+                const int e = e0 + 16 * u < count ? e0 + 16 * u : count - 1;
+                v[u] = src.ld<double>(e < last ? e + shift : e);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int u = 0; u < U; ++u)
+                if (e0 + 16 * u < count) dst.st<double>(e0 + 16 * u, v[u]);
+            }
+          };
+          if (use_ls) {
+            if (!qp.cur_is_a) {
+              copy_x(Xo, Xs, 0);
+              copy_u(Uo, Us, 0);
             }
           } else {
             // warm step (alpha = 1, mpc.py:208-212): the solution becomes the next guess, shifted (mpc.py:271-272)
-            if (lane_ok) {
-#pragma unroll 8
-              for (int t = 0; t <= T; ++t) Xg.st<S>(t * NX + j, Xs.ld<S>((t < T ? t + 1 : T) * NX + j));
-            }
-#pragma unroll 4
-            for (int e = jj; e < T * NU; e += 16) Ug.st<double>(e, Us.ld<double>(e + NU < T * NU ? e + NU : e));
+            copy_x(Xg, Xs, NS);
+            copy_u(Ug, Us, NU);
           }
         }
       }
     }
     wave_sync();
+    M4Q_PHASE_MARK(EXACT ? 15 : 2)
+#if defined(M4Q_DEV_PHASE_CLOCK)
+    if (__any(running && !(kargs()->warm_start && step > 1))) pc.count(9);      // passes with a line search
+#endif
     // back from the stash
     b = ((long)stash.get_int(g, 1) << 32) | (long)(unsigned)stash.get_int(g, 0);
     code = stash.get_int(g, 2);
@@ -475,10 +635,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
     bool fin = true;
     if (__any(solved && use_ls)) {
       KArgs* a = kargs();
-      ZView<NX, NU> z;
+      ZView<NS, NU> z;
       z.T = T; z.Xg = Xg; z.Xo = Xo; z.Xt = win.xbm; z.Ug = Ug; z.Uo = Uo; z.Ut = win.ubm;
       double al = 1.0, stepn = 0.0;
-      if (ls_diag) {
+      if constexpr (TL) {
+        line_search_tl<NX, NU, DD>(z, ldsW, ldsW + 2 * NX, ldsW + 4 * NX, jj, al, stepn);     // (the host selects TL only with diagonal costs)
+      } else if (ls_diag) {
         line_search_diag<S, NX, NU, DD>(z, ldsW, ldsW + 2 * NX, ldsW + 4 * NX, jj, al, stepn);
       } else {
         if constexpr (sizeof(S) == sizeof(cplx)) line_search<NX, NU>(z, a->Cq, a->Cqf, a->Cr, jj, al, stepn);
@@ -486,25 +648,49 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
       if (use_ls) { alpha = al; fin = stepn < a->ls_tol; }   // mpc.py:224
     }
     wave_sync();
+    M4Q_PHASE_MARK(4)
     const bool upd = solved && !fail && use_ls;       // warm steps wrote the shifted guess in the rollout
     // X_guess += alpha (X_opt - X_guess) (mpc.py:228-229)
     // (these small per-element passes are latency bound: unrolled so that several loads are in flight)
-    if (upd && lane_ok) {
-#pragma unroll 8
-      for (int t = 0; t <= T; ++t) {
-        const S xg = Xg.ld<S>(t * NX + j), xo = Xo.ld<S>(t * NX + j);
-        Xg.st<S>(t * NX + j, cadd(xg, cscale(csub(xo, xg), alpha)));
-      }
-    }
+    // (the row's 16 lanes share the (T + 1) NS contiguous elements, and a batch of U elements per lane issues all its loads
+    //  before the first store: left to the compiler the unrolled loop waited for every pair in turn - 22,000 cycles per update)
     if (upd) {
-#pragma unroll 4
-      for (int e = jj; e < T * NU; e += 16) {
-        const double ug = Ug.ld<double>(e);
-        Ug.st<double>(e, ug + alpha * (Uo.ld<double>(e) - ug));
+      constexpr int U = 12;
+      const int count = (T + 1) * NS;
+      for (int e0 = jj; e0 < count; e0 += 16 * U) {
+        S xg[U], xo[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int e = e0 + 16 * u < count ? e0 + 16 * u : count - 1;
+          xg[u] = Xg.ld<S>(e);
+          xo[u] = Xo.ld<S>(e);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (e0 + 16 * u < count) Xg.st<S>(e0 + 16 * u, cadd(xg[u], cscale(csub(xo[u], xg[u]), alpha)));
+      }
+      {
+        constexpr int V = 8;
+        const int cu = T * NU;
+        for (int e0 = jj; e0 < cu; e0 += 16 * V) {
+          double ug[V], uo[V];
+#pragma unroll
+          for (int u = 0; u < V; ++u) {
+            const int e = e0 + 16 * u < cu ? e0 + 16 * u : cu - 1;
+            ug[u] = Ug.ld<double>(e);
+            uo[u] = Uo.ld<double>(e);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < V; ++u)
+            if (e0 + 16 * u < cu) Ug.st<double>(e0 + 16 * u, ug[u] + alpha * (uo[u] - ug[u]));
+        }
       }
     }
     wave_sync();
 
+    M4Q_PHASE_MARK(8)
     // ---- rows that finished their MPC step: apply, propagate, shift ----
     bool step_done;
     {
@@ -538,32 +724,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
           op0.off = op0_off;
           ops.off = ops_off;
           const double dt = a->dt;
-          cplx xc = BasisIO<S>::template to_complex<NX, DD>(x_meas, scratch, j, jj);
+          cplx xc = Basis<S, TL>::template to_complex<NX, DD>(x_meas, tau, scratch, j, jj);
           wave_sync();
           for (int i = 0; i < mf; ++i) {
             double ui[NU];
 #pragma unroll
             for (int k = 0; k < NU; ++k)
               ui[k] = (i == 0 || !(ok && measure)) ? uapp[k] : gld(a->us, b * sUs + (long)(step - i) * NU + k);
-            if constexpr (PLANT == PLANT_HAMILTONIAN) xc = plant_hamiltonian<NX, NU, DD>(xc, ui, op0, ops, dt, scratch, j, jj);
-            else xc = plant_generator<NX, NU>(xc, ui, op0, ops, dt, j);
+            if constexpr (PLANT == PLANT_HAMILTONIAN) xc = plant_hamiltonian<NX, NU, DD>(xc, ui, op0, ops, dt, scratch, jio, jj);
+            else xc = plant_generator<NX, NU>(xc, ui, op0, ops, dt, jio);
           }
           xn = xc;
         }
-        S rn = BasisIO<S>::template to_state<NX, DD>(xn, scratch, j, jj);
+        double tnew = 0.0;
+        S rn = Basis<S, TL>::template to_state<NX, DD>(xn, scratch, j, jj, tnew);
         if (mf > 1 && __any(ok && !measure)) {
-          typename FusedProv<S, NX, NU, ORDER>::Lin lin;
+          typename FusedProv<S, NS, NU, ORDER>::Lin lin;
 #pragma unroll
           for (int k = 0; k < NU; ++k) lin.u[k] = uapp[k];
           lin.xg = x_cur;
           S pred, Bdummy[NU], ddummy;
           prov.rows(lin, x_cur, pred, Bdummy, ddummy);                 // A x + N (polyu (x) x) = A_t(u) x  (model.py:81-93)
-          const cplx pc = BasisIO<S>::template to_complex<NX, DD>(pred, scratch, j, jj);
+          const cplx pc = Basis<S, TL>::template to_complex<NX, DD>(pred, tau, scratch, j, jj);
           if (!measure) { rn = pred; xn = pc; }
         }
         if (ok) x_cur = rn;
-        if (ok && measure) x_meas = rn;
-        if (ok && lane_ok) gst(a->xs, b * sXs + (long)(step + 1) * NX + j, xn);
+        if (ok && measure) { x_meas = rn; if constexpr (TL) tau = tnew; }
+        if (ok && lane_io) gst(a->xs, b * sXs + (long)(step + 1) * NX + jio, xn);
       }
       // shift_guess (mpc.py:71-73,271-272): drop column 0, repeat the last
       const bool shift_now = ok && use_ls;          // (a warm step's rollout has already shifted)
@@ -571,10 +758,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
         for (int t0 = 0; t0 < T; t0 += 8) {
           S buf[8];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) buf[q] = Xg.ld<S>((t0 + q + 1 <= T ? t0 + q + 1 : T) * NX + j);
+          for (int q = 0; q < 8; ++q) buf[q] = Xg.ld<S>((t0 + q + 1 <= T ? t0 + q + 1 : T) * NS + j);
 #pragma unroll
           for (int q = 0; q < 8; ++q)
-            if (t0 + q < T) Xg.st<S>((t0 + q) * NX + j, buf[q]);
+            if (t0 + q < T) Xg.st<S>((t0 + q) * NS + j, buf[q]);
         }
       }
       if (shift_now && jj < NU) {
@@ -596,20 +783,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
       if constexpr (PLANT == PLANT_NONE) {
         // the caller writes xs[step+1] before the next launch; inside one launch carry what is there
         const bool carry = ok && step < row_end;
-        const cplx xc = carry ? gld(a->xs, b * sXs + (long)step * NX + j) : czero();
-        const S rn = BasisIO<S>::template to_state<NX, DD>(xc, scratch, j, jj);
-        if (carry) x_cur = rn;
+        const cplx xc = carry ? gld(a->xs, b * sXs + (long)step * NX + jio) : czero();
+        double tnew = 0.0;
+        const S rn = Basis<S, TL>::template to_state<NX, DD>(xc, scratch, j, jj, tnew);
+        if (carry) { x_cur = rn; if constexpr (TL) tau = tnew; }
       }
     }
 
+    M4Q_PHASE_MARK(5)
     // ---- rows that finished their item: publish the resumable state, free the slot ----
     const bool finished = active && step >= row_end;
     if (__any(finished)) {
       KArgs* a = kargs();
-#pragma unroll 4
-      for (int t = 0; t <= T; ++t) {
-        const cplx xc = BasisIO<S>::template to_complex<NX, DD>(Xg.ld<S>(t * NX + j), scratch, j, jj);
-        if (finished && lane_ok) gst(a->Xg, b * sX + t * NX + j, xc);
+      // (eight nodes' loads in flight at once; the basis change of each goes through LDS)
+      for (int t0 = 0; t0 <= T; t0 += 8) {
+        S v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = Xg.ld<S>((t0 + q <= T ? t0 + q : T) * NS + j);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (t0 + q <= T) {
+            const cplx xc = Basis<S, TL>::template to_complex<NX, DD>(v[q], tau, scratch, j, jj);
+            if (finished && lane_io) gst(a->Xg, b * sXc + (t0 + q) * NX + jio, xc);
+          }
+        }
       }
       if (finished) {
         for (int e = jj; e < T * NU; e += 16) gst(a->Ug, b * sU + e, Ug.ld<double>(e));
@@ -634,6 +832,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WavesFor<S>:
       }
       wave_sync();
     }
+    M4Q_PHASE_MARK(6)
+    pc.count(7);
   }
 }
 
@@ -652,7 +852,7 @@ __global__ __launch_bounds__(64) M4Q_OCC void linearize_kernel(LinArgs a) {
     const bool valid = q0 + g < a.B;
     const unsigned gl = valid ? g : (unsigned)(a.B - 1 - q0);
     wave_sync();
-    stage_model(mdl, a.models + (q0 + gl) * a.model_stride, jj);
+    stage_model<NX>(mdl, a.models + (q0 + gl) * a.model_stride, jj);
     wave_sync();
     FusedProv<cplx, NX, NU, ORDER> prov;
     prov.mdl = mdl;
@@ -812,12 +1012,15 @@ constexpr int word_block(int a, int b) {      // monomial of a word of one (b < 
   return find_monomial(c[0], c[1], c[2]);
 }
 
-template <class S>
+// N: matrix dimension (NX, or NX - 1 for the traceless blocks of the lifted generators)
+template <class S, int N>
 __global__ __launch_bounds__(64) void discretize_kernel(DiscArgs a) {
   static_assert(ORDER == 1 || ORDER == 2, "orders 1 and 2 are compiled");
   S* lds = reinterpret_cast<S*>(m4q_lds_raw);
   const LaneGeo L;
-  const int g = L.g, jj = L.jj, j = L.j;
+  const int g = L.g, jj = L.jj;
+  const int j = jj < N ? jj : N - 1;
+  constexpr int NX = N;                           // (shadows the shape's NX inside this kernel)
   constexpr int GEN_ELEMS = (1 + NU) * NX * NX;
   constexpr int W = NX * (1 + NP);
   S* G = lds + g * GEN_ELEMS;                      // [1+m][n][n] row-major, scaled
@@ -864,7 +1067,7 @@ __global__ __launch_bounds__(64) void discretize_kernel(DiscArgs a) {
         });
       }
     });
-    if (valid && L.lane_ok) {
+    if (valid && jj < N) {
 #pragma unroll
       for (int p = 0; p <= NP; ++p)
 #pragma unroll
@@ -876,7 +1079,13 @@ __global__ __launch_bounds__(64) void discretize_kernel(DiscArgs a) {
 // ---------------------------------------------------------------------------------------------
 // host-side launchers for this shape
 // ---------------------------------------------------------------------------------------------
-static size_t mpc_lds_bytes(int real_path) { return real_path ? mpc_lds_layout_bytes<double>() : mpc_lds_layout_bytes<cplx>(); }
+static size_t mpc_lds_bytes(int path) {
+  if constexpr (SQUARE) {
+    if (path == 3) return mpc_lds_layout_bytes<double, true, true>();
+    if (path == 2) return mpc_lds_layout_bytes<double, true, false>();
+  }
+  return path ? mpc_lds_layout_bytes<double>() : mpc_lds_layout_bytes<cplx>();
+}
 
 template <class K>
 static int prep_lds(K kern, size_t bytes) {
@@ -892,52 +1101,57 @@ struct LaunchOp {
   const MpcArgs& a;
   int grid;
   hipStream_t s;
-  template <class S, int PLANT, bool EXACT>
+  template <class S, int PLANT, bool EXACT, bool TL, bool TILE>
   int run() const {
-    const size_t lds = mpc_lds_layout_bytes<S>();
-    int rc = prep_lds(mpc_kernel<S, PLANT, EXACT>, lds);
+    const size_t lds = mpc_lds_layout_bytes<S, TL, TILE>();
+    int rc = prep_lds(mpc_kernel<S, PLANT, EXACT, TL, TILE>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((mpc_kernel<S, PLANT, EXACT>), dim3(grid), dim3(64), lds, s, a);
+    hipLaunchKernelGGL((mpc_kernel<S, PLANT, EXACT, TL, TILE>), dim3(grid), dim3(64), lds, s, a);
     return -(int)hipGetLastError();
   }
 };
 struct OccupancyOp {
-  template <class S, int PLANT, bool EXACT>
+  template <class S, int PLANT, bool EXACT, bool TL, bool TILE>
   int run() const {
     int nb = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mpc_kernel<S, PLANT, EXACT>, 64, mpc_lds_layout_bytes<S>());
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mpc_kernel<S, PLANT, EXACT, TL, TILE>, 64,
+                                                                 mpc_lds_layout_bytes<S, TL, TILE>());
     return e != hipSuccess ? -(int)e : nb;
   }
 };
 
-template <class S, bool EXACT, class Op>
+template <class S, bool EXACT, bool TL, bool TILE, class Op>
 static int pick_plant(const Op& op, int plant_kind) {
   if constexpr (!SQUARE) {
-    return op.template run<S, PLANT_NONE, EXACT>();
+    return op.template run<S, PLANT_NONE, EXACT, false, false>();
   } else {
-    if (plant_kind == PLANT_HAMILTONIAN) return op.template run<S, PLANT_HAMILTONIAN, EXACT>();
-    if (plant_kind == PLANT_GENERATOR) return op.template run<S, PLANT_GENERATOR, EXACT>();
-    return op.template run<S, PLANT_NONE, EXACT>();
+    if (plant_kind == PLANT_HAMILTONIAN) return op.template run<S, PLANT_HAMILTONIAN, EXACT, TL, TILE>();
+    if (plant_kind == PLANT_GENERATOR) return op.template run<S, PLANT_GENERATOR, EXACT, TL, TILE>();
+    return op.template run<S, PLANT_NONE, EXACT, TL, TILE>();
   }
 }
 
+// path: 0 complex, 1 real (Hermitian basis, NX coordinates), 2 real traceless (NX - 1 coordinates), 3 traceless with the two
+// sweeps on matrix-core tiles (clipped solve only)
 template <class Op>
-static int pick_kernel(const Op& op, int plant_kind, int real_path, int exact, int unsupported) {
+static int pick_kernel(const Op& op, int plant_kind, int path, int exact, int unsupported) {
   if constexpr (!SQUARE) {
-    if (real_path || plant_kind != PLANT_NONE) return unsupported;
+    if (path || plant_kind != PLANT_NONE) return unsupported;
   }
-  if (real_path) {
-    if constexpr (SQUARE) return exact ? pick_plant<double, true>(op, plant_kind) : pick_plant<double, false>(op, plant_kind);
+  if constexpr (SQUARE) {
+    if (path == 3 && !exact) return pick_plant<double, false, true, true>(op, plant_kind);
+    if (path >= 2) return exact ? pick_plant<double, true, true, false>(op, plant_kind) : pick_plant<double, false, true, false>(op, plant_kind);
+    if (path == 1) return exact ? pick_plant<double, true, false, false>(op, plant_kind) : pick_plant<double, false, false, false>(op, plant_kind);
   }
-  return exact ? pick_plant<cplx, true>(op, plant_kind) : pick_plant<cplx, false>(op, plant_kind);
+  return exact ? pick_plant<cplx, true, false, false>(op, plant_kind) : pick_plant<cplx, false, false, false>(op, plant_kind);
 }
 
-static int launch_mpc(const MpcArgs& a, int plant_kind, int real_path, int grid, hipStream_t s) {
-  return pick_kernel(LaunchOp{a, grid, s}, plant_kind, real_path, (a.flags & QP_EXACT_BOX) != 0, -(int)hipErrorInvalidValue);
+static int launch_mpc(const MpcArgs& a, int plant_kind, int path, int grid, hipStream_t s) {
+  return pick_kernel(LaunchOp{a, grid, s}, plant_kind, path, (a.flags & QP_EXACT_BOX) != 0, -(int)hipErrorInvalidValue);
 }
 
-static int occupancy(int plant_kind, int real_path, int exact) {
-  return pick_kernel(OccupancyOp{}, plant_kind, real_path, exact, 0);
+static int occupancy(int plant_kind, int path, int exact) {
+  return pick_kernel(OccupancyOp{}, plant_kind, path, exact, 0);
 }
 
 static int grid_for(int B) {
@@ -971,11 +1185,18 @@ static int launch_plant(const PlantArgs& a, hipStream_t s) {
   }
 }
 
-static int launch_discretize(const DiscArgs& a, int real_path, hipStream_t s) {
-  if (!SQUARE && real_path) return -(int)hipErrorInvalidValue;
+// path: 0 complex generators, 1 real n x n (lifted to the Hermitian basis), 2 real (n-1) x (n-1) (their traceless blocks)
+static int launch_discretize(const DiscArgs& a, int path, hipStream_t s) {
+  if (!SQUARE && path) return -(int)hipErrorInvalidValue;
   const size_t elems = (size_t)ROWS * (1 + NU) * NX * NX;
-  if (real_path) hipLaunchKernelGGL(discretize_kernel<double>, dim3(grid_for(a.B)), dim3(64), elems * sizeof(double), s, a);
-  else hipLaunchKernelGGL(discretize_kernel<cplx>, dim3(grid_for(a.B)), dim3(64), elems * sizeof(cplx), s, a);
+  if constexpr (SQUARE) {
+    if (path == 2) {
+      hipLaunchKernelGGL((discretize_kernel<double, NX - 1>), dim3(grid_for(a.B)), dim3(64), elems * sizeof(double), s, a);
+      return -(int)hipGetLastError();
+    }
+  }
+  if (path == 1) hipLaunchKernelGGL((discretize_kernel<double, NX>), dim3(grid_for(a.B)), dim3(64), elems * sizeof(double), s, a);
+  else hipLaunchKernelGGL((discretize_kernel<cplx, NX>), dim3(grid_for(a.B)), dim3(64), elems * sizeof(cplx), s, a);
   return -(int)hipGetLastError();
 }
 

@@ -129,10 +129,11 @@ struct ModelPitch {
   // column owners (lane j reads [r][j]) and row owners (lane r reads [r][k], lane stride = one row).
   // n = 4, 9: pitch n is conflict-free as is.  n = 16: a row is a multiple of the bank period; instead of
   // padding (17, which costs d=4 a workgroup per CU) the column is XOR-swizzled with the row.
-  static constexpr int value = NX;
+  // n = 8 (the traceless coordinates of d = 3): a row of 8 doubles puts row owners 0 and 4 on one bank; padded to 9.
+  static constexpr int value = NX == 8 ? 9 : NX;
   static __device__ __forceinline__ int at(int blk, int r, int k) {
     if constexpr (NX == 16) return (blk * NX + r) * NX + (k ^ r);
-    else return (blk * NX + r) * NX + k;
+    else return (blk * NX + r) * value + k;
   }
 };
 
@@ -182,6 +183,81 @@ template <> struct BasisIO<double> {
 };
 
 // ---------------------------------------------------------------------------------------------
+// Traceless Hermitian basis (path 2).  A trace-preserving, unital model - every Taylor-truncated Liouvillian - leaves the
+// identity component of rho invariant and decoupled from the rest, so the recursion can run on the n_s = d*d - 1 traceless
+// coordinates (the cost's cross term with the constant component vanishes when state and target have equal trace; the host
+// checks all of it, m4q_capi.hip).  The diagonal slots (a, a) of the Hermitian basis above are rotated by the orthogonal
+//   O[a][0] = 1/sqrt(d);   O[a][l] = 1/sqrt(l(l+1)) (a < l),  -l/sqrt(l(l+1)) (a == l),  0 (a > l)       l = 1 .. d-1
+// (generalised Gell-Mann diagonal matrices); slot (0, 0) becomes the trace coordinate tau = tr(rho)/sqrt(d) and is dropped:
+// traceless coordinate s = slot c - 1.  Lane conventions as above: complex data one slot per lane (jj < NX), traceless
+// data one coordinate per lane (jj < NX - 1).
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ double tl_coef(int a, int l) {      // O[a][l], l >= 1
+  const double s = 1.0 / sqrt((double)(l * (l + 1)));
+  return a < l ? s : (a == l ? -(double)l * s : 0.0);
+}
+template <int NX, int D>
+__device__ __forceinline__ double tl_to_state(cplx x, cplx* sc, int jj, double& tau) {
+  if (jj < NX) sc[jj] = x;
+  wave_sync();
+  const int s = jj < NX - 1 ? jj : NX - 2;
+  const int c = s + 1, a = c / D, b = c - (c / D) * D;
+  const double rs = 0.70710678118654752440;
+  double t = 0.0, diag = 0.0;
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    const double xk = sc[k * D + k].re;
+    t += xk;
+    diag = fma(tl_coef<D>(k, a > 0 ? a : 1), xk, diag);        // (used when a == b: l = a >= 1)
+  }
+  tau = t * (1.0 / sqrt((double)D));
+  const cplx own = sc[c], partner = sc[b * D + a];
+  wave_sync();
+  if (a == b) return diag;
+  return a < b ? (own.re + partner.re) * rs : (own.im - partner.im) * rs;
+}
+template <int NX, int D>
+__device__ __forceinline__ cplx tl_to_complex(double r, double tau, cplx* scc, int jj) {
+  double* sc = reinterpret_cast<double*>(scc);
+  if (jj < NX - 1) sc[jj] = r;
+  wave_sync();
+  const int c = jj < NX ? jj : NX - 1, a = c / D, b = c - (c / D) * D;
+  const double rs = 0.70710678118654752440;
+  cplx out;
+  if (a == b) {
+    double v = tau * (1.0 / sqrt((double)D));
+#pragma unroll
+    for (int l = 1; l < D; ++l) v = fma(tl_coef<D>(a, l), sc[l * D + l - 1], v);
+    out = mk(v, 0.0);
+  } else {
+    const double own = sc[c - 1], partner = sc[b * D + a - 1];
+    out = a < b ? mk(own * rs, -partner * rs) : mk(partner * rs, own * rs);
+  }
+  wave_sync();
+  return out;
+}
+
+// What the closed-loop kernel calls: S, and whether the state lives in the traceless coordinates (TL).  `tau` is the member's
+// trace coordinate: written by to_state, read by to_complex (ignored unless TL).
+template <class S, bool TL> struct Basis {
+  template <int NX, int D> static __device__ __forceinline__ S to_state(cplx x, cplx* sc, int j, int jj, double&) {
+    return BasisIO<S>::template to_state<NX, D>(x, sc, j, jj);
+  }
+  template <int NX, int D> static __device__ __forceinline__ cplx to_complex(S r, double, cplx* sc, int j, int jj) {
+    return BasisIO<S>::template to_complex<NX, D>(r, sc, j, jj);
+  }
+};
+template <> struct Basis<double, true> {
+  template <int NX, int D> static __device__ __forceinline__ double to_state(cplx x, cplx* sc, int, int jj, double& tau) {
+    return tl_to_state<NX, D>(x, sc, jj, tau);
+  }
+  template <int NX, int D> static __device__ __forceinline__ cplx to_complex(double r, double tau, cplx* sc, int, int jj) {
+    return tl_to_complex<NX, D>(r, tau, sc, jj);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
 // Linearisation providers.  fetch(t): the per-t operands that come from memory (issued one horizon
 // index ahead of their use so the loads overlap the previous index's arithmetic).  col(): column j of
 // A_t.  rows(): for the row this lane owns, (A_t v)_j for a distributed vector v, row j of B_t and
@@ -193,21 +269,9 @@ template <> struct BasisIO<double> {
 template <int NX, int NU, int ORDER>
 constexpr bool batch_fits() { return NX <= 9 && (1 + PowTab<NU, ORDER>::NP) * NX <= 27; }
 
-// one model element from LDS.  (M4Q_EXP & 256: timing-only ablation, results wrong - an opaque register copy instead of
-// the LDS read: what the launch would take without any LDS traffic or latency for the model)
-#ifndef M4Q_EXP
-#define M4Q_EXP 0
-#endif
+// one model element from LDS
 template <class S>
-__device__ __forceinline__ S mld(const S* mdl, int idx) {
-  if constexpr ((M4Q_EXP & 256) != 0) {
-    double v = 1e-3 * (double)(idx & 7);
-    asm volatile("" : "+v"(v));
-    return from_real<S>(v);
-  } else {
-    return mdl[idx];
-  }
-}
+__device__ __forceinline__ S mld(const S* mdl, int idx) { return mdl[idx]; }
 
 // Real path, backward sweep: the column form (for A_t's column) and the row form (for A_t xbar and row j of B_t) of the model
 // are read from LDS in ONE batch at the top of the horizon index - at that point only P and the prefetched operands are live,
@@ -379,6 +443,21 @@ struct FusedProv {
       cmac_r(dlt, b, -l.u[k]);
     }
   }
+  // row j of B_t alone (the adjoint pass needs neither A_t v nor Delta_t)
+  __device__ __forceinline__ void brows(const Lin& l, S (&Brow)[NU]) const {
+    if constexpr (ORDER == 1) {
+#pragma unroll
+      for (int k = 0; k < NU; ++k) {
+        S row[NX];
+#pragma unroll
+        for (int c = 0; c < NX; ++c) row[c] = mld(mdl, ModelPitch<NX>::at(1 + k, j, c));
+        Brow[k] = dot_lane_index<false, false, NX>(l.xg, row);          // monomial p is u_p (order1_is_identity)
+      }
+    } else {
+      S av, dlt;
+      rows(l, zero_of<S>(), av, Brow, dlt);
+    }
+  }
   // B_t[:,k] = sum_p (N_p x) c_kp dmono_kp(u)  (linearize.py:50-59);  Delta_t = f - A_t x - B_t u = -B_t u (:68-69)
   __device__ __forceinline__ void rows(const Lin& l, S v, S& av, S (&Brow)[NU], S& dlt) const {
     Poly<NU, ORDER> po;
@@ -474,6 +553,10 @@ struct ExplicitProv {
     col(l, Ac);
     rows(l, v, av, Brow, dlt);
   }
+  __device__ __forceinline__ void brows(const Lin& l, cplx (&Brow)[NU]) const {
+#pragma unroll
+    for (int k = 0; k < NU; ++k) Brow[k] = B_ls.ld<cplx>((l.t * NX + j) * NU + k);
+  }
   __device__ __forceinline__ void rows(const Lin& l, cplx v, cplx& av, cplx (&Brow)[NU], cplx& dlt) const {
     cplx arow[NX];
 #pragma unroll
@@ -548,11 +631,10 @@ struct PinCtx {
   GView stat;
   Box box;
   double lo0[NU], hi0[NU];
-  // derive (per row): the sweep first re-derives this row's working set from the gradient at the iterate (Xk, Uk) - the
-  // adjoint recursion lam_t = Q e_t + A_t^H lam_{t+1}, g_t = R (u_t - ub_t) + Re B_t^H lam_{t+1} runs inside the sweep:
-  // a control is pinned iff it sits on a bound with the gradient pushing outward.  any_derive: some row of the wavefront
-  // does (uniform).  nchg receives the number of entries that changed with respect to what `stat` held.
-  bool derive = false, any_derive = false;
+  // adjoint_pass (per row, `derive`): re-derives this row's working set from the gradient at the iterate (Xk, Uk) - the adjoint
+  // recursion lam_t = Q e_t + A_t^H lam_{t+1}, g_t = R (u_t - ub_t) + Re B_t^H lam_{t+1}: a control is pinned iff it sits on a
+  // bound with the gradient pushing outward.  nchg receives the number of entries that changed with respect to what `stat` held.
+  bool derive = false;
   GView Xk, Uk;
   int nchg = 0;
   // pinned value of control k at horizon index t, or free
@@ -578,19 +660,13 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
     for (int i = 0; i < NX; ++i) Pc[i] = Qt[i * NX + j];
     if (ref) pv = cneg(qrow_times<NX>(Qt, xb_next, j));
   }
-  S lam = zero_of<S>();        // PINNED + derive: adjoint of the iterate's trajectory
-  if constexpr (PINNED) {
-    pin->nchg = 0;
-    if (pin->any_derive) lam = qrow_times<NX>(cost.q(T, T), csub(pin->Xk.template ld<S>(T * NX + j), xb_next), j);
-  }
   // operands of horizon index t are fetched while index t+1 is being worked on.  The loop below runs two indices per
   // trip: the two operand sets and the two copies of (P, p) swap roles, so that neither is ever copied.
   struct Ops {
     typename Prov::Lin lin;
     S xb;
     double ub[NU];
-    double stv[NU], uk[NU];   // PINNED: working set and iterate's controls at this index
-    S xk;                     // PINNED + derive: iterate's state
+    double stv[NU];           // PINNED: working set at this index
   };
   auto load = [&](int t) __attribute__((always_inline)) {
     Ops o;
@@ -601,11 +677,6 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
     if constexpr (PINNED) {
 #pragma unroll
       for (int k = 0; k < NU; ++k) o.stv[k] = pin->stat.template ld<double>(t * NU + k);
-      if (pin->any_derive) {
-#pragma unroll
-        for (int k = 0; k < NU; ++k) o.uk[k] = pin->Uk.template ld<double>(t * NU + k);
-        o.xk = pin->Xk.template ld<S>(t * NX + j);
-      }
     }
     return o;
   };
@@ -613,7 +684,7 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
   // read-to-use latency of the model at every horizon index: the ROW form of the model is read once per sweep and kept in
   // registers (measured A/B on config 4: 92.9 -> 85.8 ms; profiles/r02_ab_experiments.txt)
   constexpr bool HOIST = M4Q_HOIST_MODEL && std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && sizeof(S) == sizeof(double) &&
-                         NX == 16;
+                         NX >= 15;
   ModelRegs<S, NX, NU, Prov::ORDER_> mregs;
   if constexpr (HOIST) mregs.load_rows(prov.mdl, j);
   // constant target: real fused path with batched (n <= 9) or hoisted (n = 16, mode 2) model reads
@@ -671,13 +742,10 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
       for (int l = k; l < NU; ++l) {
         const S prod = cmul(BhP[k], Brow[l]);
         const S rkl = Rt[k * NU + l];
-        // (M4Q_EXP & 512: timing-only ablation, results wrong - no cross-lane sums in the sweep)
-        if constexpr ((M4Q_EXP & 512) != 0) g[k][l] = l == k ? mk(real_of(rkl) + real_of(prod) * real_of(prod), 0.0) : as_cplx(cadd(rkl, prod));
-        else if (l == k) g[k][l] = mk(real_of(rkl) + rowsum<NX>(real_of(prod)), 0.0);
+        if (l == k) g[k][l] = mk(real_of(rkl) + rowsum<NX>(real_of(prod)), 0.0);
         else g[k][l] = as_cplx(cadd(rkl, rowsum<NX>(prod)));
       }
-      if constexpr ((M4Q_EXP & 512) != 0) h[k] = cmul(cconj(Brow[k]), w);
-      else h[k] = rowsum<NX>(cmul(cconj(Brow[k]), w));
+      h[k] = rowsum<NX>(cmul(cconj(Brow[k]), w));
     }
     // Hh[l] = (B^H P A_t)[l][j] = sum_i BhP[l][i] A_t[i][j]
     S Hh[NU];
@@ -685,6 +753,7 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
     for (int l = 0; l < NU; ++l) Hh[l] = dot_lane_index<false, false, NX>(BhP[l], Ac);
     bool fix[NU];
     double dufix[NU];
+    S Hraw[NU], hraw[NU], Graw[NU][NU];          // PINNED only
 #pragma unroll
     for (int k = 0; k < NU; ++k) { fix[k] = false; dufix[k] = 0.0; }
     if constexpr (PINNED) {
@@ -693,31 +762,6 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
       double stv[NU];
 #pragma unroll
       for (int k = 0; k < NU; ++k) stv[k] = cur.stv[k];
-      if (pin->any_derive) {
-        double uk[NU];
-#pragma unroll
-        for (int k = 0; k < NU; ++k) uk[k] = cur.uk[k];
-#pragma unroll
-        for (int k = 0; k < NU; ++k) {
-          double gk = rowsum<NX>(real_of(cmul(cconj(Brow[k]), lam)));
-#pragma unroll
-          for (int l = 0; l < NU; ++l) gk = fma(real_of(Rt[k * NU + l]), uk[l] - ub[l], gk);
-          double lo, hi;
-          pin->box.template at<NU>(t, k, pin->lo0, pin->hi0, lo, hi);
-          const double eps = 1e-12 * pin->box.sat;
-          double sv = 0.0;
-          if (uk[k] <= lo + eps && gk > 0.0) sv = -1.0;
-          if (uk[k] >= hi - eps && gk < 0.0) sv = 1.0;
-          if (hi - lo <= 2 * eps) sv = 1.0;                // degenerate interval: nothing to optimise
-          if (pin->derive) {
-            pin->nchg += stv[k] != sv ? 1 : 0;
-            stv[k] = sv;
-            if (store_ok && j == 0) pin->stat.template st<double>(t * NU + k, sv);
-          }
-        }
-        const S e = csub(cur.xk, xb);
-        lam = dot_lane_index<false, true, NX>(lam, Ac, qrow_times<NX>(cost.q(t, T), e, j));   // Q_t e_t + A_t^H lam
-      }
 #pragma unroll
       for (int k = 0; k < NU; ++k) {
         double lo, hi;
@@ -732,6 +776,14 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
           const cplx gkl = k <= l ? g[k][l] : cconj(g[l][k]);
           cmac_r(h[k], from_cplx<S>(gkl), dufix[l]);
         }
+      }
+      // (what the stage's gradient is for a pinned control, kept for its multiplier row below: H_k, h_k + G_k. du_pinned, G_k.)
+#pragma unroll
+      for (int k = 0; k < NU; ++k) {
+        Hraw[k] = Hh[k];
+        hraw[k] = h[k];
+#pragma unroll
+        for (int l = 0; l < NU; ++l) Graw[k][l] = from_cplx<S>(k <= l ? g[k][l] : cconj(g[l][k]));
       }
 #pragma unroll
       for (int k = 0; k < NU; ++k) {
@@ -755,13 +807,34 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
       Kx[k] = cneg(a);
       kk[k] = fix[k] ? from_real<S>(dufix[k]) : cneg(b);
     }
+    // what is stored for the rollout: the gain row [Kx | k] of a free control; for a PINNED one (whose gain row would be the
+    // trivial [0 | du_fix]) the affine form of its multiplier along the policy's own trajectory,
+    //   mu_k(dx) = [H_k + sum_{l free} G_kl Kx_l] dx + h_k + sum_l G_kl du_l        (the stage's gradient with respect to u_k)
+    // so that the rollout - which forms row . dx + const for every control anyway - can tell whether the face minimiser it has
+    // just produced satisfies the sign conditions (KKT), without an adjoint pass.
+    S Kst[NU], kst[NU];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) { Kst[k] = Kx[k]; kst[k] = kk[k]; }
+    if constexpr (PINNED) {
+#pragma unroll
+      for (int k = 0; k < NU; ++k) {
+        S m = Hraw[k], c0 = hraw[k];
+#pragma unroll
+        for (int l = 0; l < NU; ++l) {
+          cmac(m, Graw[k][l], fix[l] ? zero_of<S>() : Kx[l]);
+          cmac(c0, Graw[k][l], fix[l] ? zero_of<S>() : kk[l]);           // (pinned l: G_kl du_fix_l is already inside hraw)
+        }
+        Kst[k] = fix[k] ? m : Kx[k];
+        kst[k] = fix[k] ? c0 : kk[k];
+      }
+    }
     if (store_ok) {
       const unsigned gt = (unsigned)t * (NX + 1) * NU;
 #pragma unroll
-      for (int k = 0; k < NU; ++k) gains.st<S>(gt + j * NU + k, Kx[k]);
+      for (int k = 0; k < NU; ++k) gains.st<S>(gt + j * NU + k, Kst[k]);
       if (j == 0) {
 #pragma unroll
-        for (int k = 0; k < NU; ++k) gains.st<S>(gt + NX * NU + k, kk[k]);
+        for (int k = 0; k < NU; ++k) gains.st<S>(gt + NX * NU + k, kst[k]);
       }
     }
 
@@ -845,6 +918,79 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Working set of the exact box-QP solver from the gradient at the iterate (Xk, Uk): the adjoint recursion alone, no Riccati
+// arithmetic - ~100 vector instructions per horizon index against ~800 of the pinned sweep.  (Round 2 ran it inside the sweep:
+// "no pass of its own", but then every solve ended with a full sweep whose only product was the verdict "nothing changed".)
+// Operands are fetched PF indices ahead (an index is too short to hide the workspace's latency behind the previous one; four
+// ahead spilled inside the loop).
+// ---------------------------------------------------------------------------------------------
+template <class S, int NX, int NU, class Prov>
+__device__ __forceinline__ void adjoint_pass(const Prov& prov, int T, const Window& win, const CostRef<S>& cost, PinCtx<NU>& pin, int j,
+                                             bool store_ok) {
+  constexpr int PF = 2;
+  struct Ops {
+    typename Prov::Lin lin;
+    S xb, xk;
+    double ub[NU], stv[NU], uk[NU];
+  };
+  auto load = [&](int t) __attribute__((always_inline)) {
+    Ops o;
+    o.lin = prov.fetch(t);
+    o.xb = win.xbm.ld<S>(t * NX + j);
+    o.xk = pin.Xk.template ld<S>(t * NX + j);
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+      o.ub[k] = win.ubm.ld<double>(t * NU + k);
+      o.stv[k] = pin.stat.template ld<double>(t * NU + k);
+      o.uk[k] = pin.Uk.template ld<double>(t * NU + k);
+    }
+    return o;
+  };
+  pin.nchg = 0;
+  S lam = qrow_times<NX>(cost.q(T, T), csub(pin.Xk.template ld<S>(T * NX + j), win.xbm.ld<S>(T * NX + j)), j);
+  auto step = [&](int t, const Ops& cur) __attribute__((always_inline)) {
+    S Ac[NX], Brow[NU];
+    prov.col(cur.lin, Ac);
+    prov.brows(cur.lin, Brow);
+    const S* Rt = cost.r(t);
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+      double gk = rowsum<NX>(real_of(cmul(cconj(Brow[k]), lam)));
+#pragma unroll
+      for (int l = 0; l < NU; ++l) gk = fma(real_of(Rt[k * NU + l]), cur.uk[l] - cur.ub[l], gk);
+      double lo, hi;
+      pin.box.template at<NU>(t, k, pin.lo0, pin.hi0, lo, hi);
+      const double eps = 1e-12 * pin.box.sat;
+      double sv = 0.0;
+      if (cur.uk[k] <= lo + eps && gk > 0.0) sv = -1.0;
+      if (cur.uk[k] >= hi - eps && gk < 0.0) sv = 1.0;
+      if (hi - lo <= 2 * eps) sv = 1.0;                // degenerate interval: nothing to optimise
+      if (pin.derive) {
+        pin.nchg += cur.stv[k] != sv ? 1 : 0;
+        if (store_ok && j == 0) pin.stat.template st<double>(t * NU + k, sv);
+      }
+    }
+    const S e = csub(cur.xk, cur.xb);
+    lam = dot_lane_index<false, true, NX>(lam, Ac, qrow_times<NX>(cost.q(t, T), e, j));   // Q_t e_t + A_t^H lam
+  };
+  Ops ring[PF];
+#pragma unroll
+  for (int i = 0; i < PF; ++i) ring[i] = load(T - 1 - i > 0 ? T - 1 - i : 0);
+  int t = T - 1;
+  for (; t >= PF - 1; t -= PF) {
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      M4Q_NO_HOIST();
+      step(t - i, ring[i]);
+      ring[i] = load(t - i - PF > 0 ? t - i - PF : 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < PF - 1; ++i)
+    if (t - i >= 0) step(t - i, ring[i]);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Forward rollout with clipping (lqr.py:67-79; dynamics with Delta: optimize.py:41).
 // x distributed (lane j holds x_t[j]).  WANT_COST: return the objective (replicated over the row);
 // otherwise return sum |x|^2 + sum u^2, which is finite exactly when every state and control is -
@@ -895,7 +1041,7 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
     return o;
   };
   constexpr bool HOIST = M4Q_HOIST_MODEL && std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && sizeof(S) == sizeof(double) &&
-                         NX == 16;
+                         NX >= 15;
   ModelRegs<S, NX, NU, Prov::ORDER_> mregs;
   if constexpr (HOIST) mregs.load_rows(prov.mdl, j);
   // one horizon index: `cur` holds its operands, those of the next index are fetched into `nxt` meanwhile.  The loop
@@ -1009,6 +1155,8 @@ struct RolloutInfo {
   double dmax;       // max |u - u^k|
   bool outside;      // some free control left the box (before clipping)
   double alpha;      // ratio test: largest step along u^k -> u that stays in the box (<= 1)
+  int nbad;          // pinned controls whose multiplier along this rollout has the wrong sign (meaningful when !outside: the
+                     // rollout is then the minimiser over its face, and nbad == 0 is the KKT test)
 };
 
 // closed-loop rollout of the policy in `gains` (pinned controls sit on their bound), with (clip) or without clipping
@@ -1022,6 +1170,7 @@ __device__ __forceinline__ double rollout_policy(const Prov& prov, int T, S x0, 
   info.dmax = 0.0;
   info.outside = false;
   info.alpha = 1.0;
+  info.nbad = 0;
   double cx = 0.0, cu = 0.0;
   // operands of horizon index t+1 are fetched while index t computes (two sets swapping roles, as in rollout_forward): the
   // step is a short dependent chain and every operand comes from the workspace, i.e. from beyond the L2
@@ -1065,8 +1214,12 @@ __device__ __forceinline__ double rollout_policy(const Prov& prov, int T, S x0, 
       const double pv = cur.st[k] > 0.0 ? hi : lo;                 // pinned value (PinCtx::pinned)
       const double uk = cur.uk[k];
       const double part = real_of(cmul(cur.Kx[k], dx));
-      const double v = rowsum<NX>(part) + cur.kre[k] + cur.ub[k];
+      const double lin = rowsum<NX>(part) + cur.kre[k];            // free: du = Kx dx + k;  pinned: its multiplier (riccati_backward)
+      const double v = lin + cur.ub[k];
       un[k] = fixd ? pv : v;
+      // pinned at the upper bound wants a gradient pushing up (mu < 0), at the lower one mu > 0 - the rule of adjoint_pass;
+      // a degenerate interval is pinned whatever the sign
+      if (fixd && hi - lo > 2e-12 * pin.box.sat && !(cur.st[k] > 0.0 ? lin < 0.0 : lin > 0.0)) ++info.nbad;
       const bool above = un[k] > hi, below = un[k] < lo;
       if (above || below) {
         info.outside = true;
@@ -1199,9 +1352,35 @@ struct BoxQpRow {
 template <class S, int NX, int NU, class Prov>
 __device__ __forceinline__ bool box_qp_iterate(const Prov& prov, int T, S x0, const Window& win, const CostRef<S>& cost, int flags,
                                                const GView& gains, PinCtx<NU>& pin, GView Xa, GView Ua, GView Xb, GView Ub,
-                                               BoxQpRow& r, int j, int jj, bool lane_ok) {
+                                               BoxQpRow& r, int j, int jj, bool lane_ok, PhaseClock* pc = nullptr) {
+  PhaseClock none;
+  PhaseClock& clk = pc ? *pc : none;
   const bool was_busy = r.busy;
+  // (every sweep of the iteration gets the horizon through an opaque copy: loop bounds and unroll-remainder predicates derived
+  //  from it then live inside that sweep instead of across the whole iteration, where they were spilled to VGPR lanes)
+  auto Tf = [&]() __attribute__((always_inline)) { int v = T; asm volatile("" : "+s"(v)); return v; };
   const Box& box = pin.box;
+  // Rows whose iterate has just changed (or that start a solve) re-derive their working set from the gradient at the iterate
+  // (adjoint recursion only); a face minimiser whose working set comes back unchanged has multipliers of the right sign: KKT,
+  // done.  ONE such pass per call, at its start, serves the rows that start a solve and the rows the previous call moved: the
+  // KKT verdict of a face minimiser normally comes from the policy rollout itself (RolloutInfo::nbad), so a solve still ends
+  // in the pass of its last Riccati sweep.  (Round 3 until then: a second pass at the end of the call, 27 % of the launch.)
+  auto derive_working_sets = [&]() __attribute__((always_inline)) {
+    const bool adj = r.busy && r.need_adj;
+    if (__any(adj)) {
+      pin.derive = adj;
+      pin.Xk = Xa; pin.Uk = Ua;
+      pin.Xk.off = r.cur_is_a ? Xa.off : Xb.off;
+      pin.Uk.off = r.cur_is_a ? Ua.off : Ub.off;
+      adjoint_pass<S, NX, NU>(prov, Tf(), win, cost, pin, j, adj && lane_ok);
+      wave_sync();
+      if (adj && r.face_min && pin.nchg == 0) { r.busy = false; ++r.stats.end_kkt; }
+      if (adj) { r.need_adj = false; r.face_min = false; }
+    }
+  };
+  clk.mark(15);
+  derive_working_sets();                     // (rows that start a solve, rows that moved in the previous call)
+  clk.mark(1);
   // per-row source / destination: same wave-uniform bases, lane offsets swapped
   GView Xk = Xa, Uk = Ua, Xc = Xb, Uc = Ub;
   Xk.off = r.cur_is_a ? Xa.off : Xb.off;
@@ -1209,28 +1388,21 @@ __device__ __forceinline__ bool box_qp_iterate(const Prov& prov, int T, S x0, co
   Xc.off = r.cur_is_a ? Xb.off : Xa.off;
   Uc.off = r.cur_is_a ? Ub.off : Ua.off;
   if (__any(r.busy)) {
-    const bool going0 = r.busy;
-    // the sweep re-derives the working set of the rows that need it (adjoint recursion inside the sweep)
-    const bool adj = r.busy && r.need_adj;
-    pin.derive = adj;
-    pin.any_derive = __any(adj);
-    pin.Xk = Xk;
-    pin.Uk = Uk;
-    if (going0) ++r.iters;
-    riccati_backward<S, NX, NU, Prov, true>(prov, T, win, cost, flags, gains, j, going0 && lane_ok, &pin);
-    wave_sync();
-    if (adj && r.face_min && pin.nchg == 0) { r.busy = false; ++r.stats.end_kkt; }   // face minimiser, multipliers of the right sign
     const bool going = r.busy;
-    r.need_adj = false;
-    r.face_min = false;
-    RolloutInfo ri;
-    const double Jc = rollout_policy<S, NX, NU>(prov, T, x0, win, cost, gains, pin, Uk, true, Xc, Uc, j, going && lane_ok, ri);
+    if (going) ++r.iters;
+    riccati_backward<S, NX, NU, Prov, true>(prov, Tf(), win, cost, flags, gains, j, going && lane_ok, &pin);
     wave_sync();
+    clk.mark(10);
+    RolloutInfo ri;
+    const double Jc = rollout_policy<S, NX, NU>(prov, Tf(), x0, win, cost, gains, pin, Uk, true, Xc, Uc, j, going && lane_ok, ri);
+    wave_sync();
+    clk.mark(11);
     if (going) ++r.stats.sweeps;
     bool moved = false;
     if (going && !(ri.dmax > 1e-13 * box.sat)) {
       // the policy reproduces the iterate: it is the minimiser of its face (or NaN)
       if (!(ri.dmax == ri.dmax) || ++r.stalls > 1) { r.busy = false; ++r.stats.end_precision; }
+      else if (!ri.outside && ri.nbad == 0) { r.busy = false; ++r.stats.end_kkt; }      // face minimiser, multipliers of the right sign
       r.face_min = true;
       r.need_adj = true;
     } else if (going && (Jc < r.Jk || (!ri.outside && Jc <= r.Jk + 1e-12 * fabs(r.Jk) && r.stalls < 2))) {
@@ -1241,6 +1413,9 @@ __device__ __forceinline__ bool box_qp_iterate(const Prov& prov, int T, S x0, co
       r.Jk = Jc;
       r.face_min = !ri.outside;
       r.need_adj = true;
+      // nothing clipped: the new iterate minimises J over the face; if every pinned control's multiplier has the right sign it
+      // is the optimum (KKT) - known from the rollout itself.  Otherwise the working set is re-derived from the gradient.
+      if (!ri.outside && ri.nbad == 0) { r.busy = false; ++r.stats.end_kkt; }
     } else if (going && !ri.outside) {
       r.busy = false;                                          // face minimiser without decrease: working precision
       ++r.stats.end_precision;
@@ -1249,17 +1424,29 @@ __device__ __forceinline__ bool box_qp_iterate(const Prov& prov, int T, S x0, co
     const bool ratio = r.busy && going && !moved && !r.face_min;
     if (__any(ratio)) {
       RolloutInfo rn;
-      const double Jn = rollout_policy<S, NX, NU>(prov, T, x0, win, cost, gains, pin, Uk, false, Xc, Uc, j, ratio && lane_ok, rn);
+      const double Jn = rollout_policy<S, NX, NU>(prov, Tf(), x0, win, cost, gains, pin, Uk, false, Xc, Uc, j, ratio && lane_ok, rn);
       wave_sync();
+      clk.mark(12);
       if (ratio) {
         ++r.stats.ratio_steps;
         const double al = rn.alpha;
         // blend in place: trial = iterate + al (Newton - iterate); blocking controls land exactly on their bound
-        if (lane_ok) {
-#pragma unroll 4
-          for (int t = 0; t <= T; ++t) {
-            const S xk = Xk.ld<S>(t * NX + j), xn = Xc.ld<S>(t * NX + j);
-            Xc.st<S>(t * NX + j, cadd(xk, cscale(csub(xn, xk), al)));
+        // (the row's 16 lanes share the contiguous elements; a batch issues all its loads before the first store)
+        {
+          constexpr int U = 12;
+          const int count = (T + 1) * NX;
+          for (int e0 = jj; e0 < count; e0 += 16 * U) {
+            S xk[U], xn[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              const int e = e0 + 16 * u < count ? e0 + 16 * u : count - 1;
+              xk[u] = Xk.ld<S>(e);
+              xn[u] = Xc.ld<S>(e);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+              if (e0 + 16 * u < count) Xc.st<S>(e0 + 16 * u, cadd(xk[u], cscale(csub(xn[u], xk[u]), al)));
           }
         }
         for (int e = jj; e < T * NU; e += 16) {
@@ -1282,6 +1469,7 @@ __device__ __forceinline__ bool box_qp_iterate(const Prov& prov, int T, S x0, co
         if (r.stalls > 2 * NU * T) { r.busy = false; ++r.stats.end_cap; }
       }
     }
+    clk.mark(13);
     if (going && moved) r.cur_is_a = !r.cur_is_a;
     if (r.busy && r.iters >= 100 + 2 * NU * T) { r.busy = false; ++r.stats.end_cap; }   // (the path adds at least one control per step)
     wave_sync();
@@ -1416,6 +1604,130 @@ __device__ __forceinline__ void line_search_diag(const ZView<NX, NU>& z, const d
     num = fma(w * e, d, num);
     den = fma(w * d, d, den);
     nrm = fma(d, d, nrm);
+  }
+  num = rowsum<16>(num);
+  den = rowsum<16>(den);
+  nrm = rowsum<16>(nrm);
+  alpha = -num / den;
+  step_norm = fabs(alpha) * sqrt(nrm);
+}
+
+// The same diagonal-cost line search when the trajectories are held in the traceless coordinates (n_s = NX - 1 per node).
+// The reference's sums run over the slots of vec(rho): lane c < NX takes slot c.  An off-diagonal slot pair is one traceless
+// coordinate each (as above); a diagonal slot (a, a) is the combination sum_l O[a][l] r_l of the d - 1 traceless diagonal
+// coordinates (the trace coordinate of guess, solution and target is the same number: it drops out of e and d).
+template <int NX, int NU, int D>
+__device__ __forceinline__ void line_search_tl(const ZView<NX - 1, NU>& z, const double* wq, const double* wqf, const double* wr,
+                                               int jj, double& alpha, double& step_norm) {
+  constexpr int NS = NX - 1, NO = NX - D;        // traceless coordinates per node; off-diagonal slots per node
+  const int T = z.T;
+  const int nxt = NX * (T + 1);
+  double num = 0.0, den = 0.0, nrm = 0.0;
+  auto weight = [&](int q) {
+    const int blk = q / (2 * NX);
+    const int r = q - blk * (2 * NX);
+    return (blk == T ? wqf : wq)[r];
+  };
+  // All 16 lanes of the row share the (node, slot) pairs, and every batch of U pairs per lane issues ALL its loads before the
+  // first use: the pass is bound by memory latency (the trajectories come from beyond the L2), and left to the compiler an
+  // unrolled loop waits for each pair's loads in turn (measured: 60,000 cycles per line search, a third of a QP solve;
+  // profiles/r03_phase_clock.txt).
+  // (a) off-diagonal slots: one traceless coordinate each.  i-th off-diagonal slot of a node: c = i + 1 + i / D.
+  {
+    constexpr int U = 8;
+    const int count = NO * (T + 1);
+    for (int f0 = jj; f0 < count; f0 += 16 * U) {
+      double g[U], o[U], tg[U];
+      int cc[U], tt[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int f = f0 + 16 * u < count ? f0 + 16 * u : count - 1;
+        const int t = f / NO, i = f - t * NO;
+        const int c = i + 1 + i / D;
+        cc[u] = c; tt[u] = t;
+        g[u] = z.Xg.template ld<double>(t * NS + c - 1);
+        o[u] = z.Xo.template ld<double>(t * NS + c - 1);
+        tg[u] = z.Xt.template ld<double>(t * NS + c - 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = cc[u], t = tt[u], a = c / D, b = c - a * D;
+        const double e = g[u] - tg[u], d = o[u] - g[u];
+        const int q0 = c * (T + 1) + t;           // Z slot of Re x_c; Im sits nxt further
+        const int off = a > b ? nxt : 0;          // antisymmetric coordinates live in the imaginary halves
+        double w = 0.5 * (weight(q0 + off) + weight((b * D + a) * (T + 1) + t + off));
+        w = f0 + 16 * u < count ? w : 0.0;
+        num = fma(w * e, d, num);
+        den = fma(w * d, d, den);
+        nrm = fma(f0 + 16 * u < count ? d : 0.0, d, nrm);
+      }
+    }
+  }
+  // (b) diagonal slots (a, a): the combination sum_l O[a][l] r_l of the d - 1 traceless diagonal coordinates
+  {
+    constexpr int U = 4;
+    const int count = D * (T + 1);
+    for (int f0 = jj; f0 < count; f0 += 16 * U) {
+      double g[U][D - 1], o[U][D - 1], tg[U][D - 1];
+      int aa[U], tt[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int f = f0 + 16 * u < count ? f0 + 16 * u : count - 1;
+        const int t = f / D, a = f - t * D;
+        aa[u] = a; tt[u] = t;
+#pragma unroll
+        for (int l = 1; l < D; ++l) {
+          g[u][l - 1] = z.Xg.template ld<double>(t * NS + l * D + l - 1);
+          o[u][l - 1] = z.Xo.template ld<double>(t * NS + l * D + l - 1);
+          tg[u][l - 1] = z.Xt.template ld<double>(t * NS + l * D + l - 1);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int a = aa[u], t = tt[u];
+        double gs = 0.0, os = 0.0, ts = 0.0;
+#pragma unroll
+        for (int l = 1; l < D; ++l) {
+          const double cf = tl_coef<D>(a, l);
+          gs = fma(cf, g[u][l - 1], gs);
+          os = fma(cf, o[u][l - 1], os);
+          ts = fma(cf, tg[u][l - 1], ts);
+        }
+        const double e = gs - ts, d = os - gs;
+        const double w = f0 + 16 * u < count ? weight((a * D + a) * (T + 1) + t) : 0.0;
+        num = fma(w * e, d, num);
+        den = fma(w * d, d, den);
+        nrm = fma(f0 + 16 * u < count ? d : 0.0, d, nrm);
+      }
+    }
+  }
+  // (c) controls: Z = [U.flatten() (k-major over (m, T)), zeros]; block b covers 2m consecutive slots
+  {
+    constexpr int U = 8;
+    const int count = NU * T;
+    for (int f0 = jj; f0 < count; f0 += 16 * U) {
+      double g[U], o[U], tg[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int f = f0 + 16 * u < count ? f0 + 16 * u : count - 1;
+        const int k = f / T, t = f - k * T;
+        g[u] = z.Ug.template ld<double>(t * NU + k);
+        o[u] = z.Uo.template ld<double>(t * NU + k);
+        tg[u] = z.Ut.template ld<double>(t * NU + k);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int f = f0 + 16 * u;
+        const double w = f < count ? wr[f % (2 * NU)] : 0.0;
+        const double e = g[u] - tg[u], d = o[u] - g[u];
+        num = fma(w * e, d, num);
+        den = fma(w * d, d, den);
+        nrm = fma(f < count ? d : 0.0, d, nrm);
+      }
+    }
   }
   num = rowsum<16>(num);
   den = rowsum<16>(den);

@@ -233,7 +233,7 @@ class _HeldControl:
 
 def open_session(x0, models, dim_u, order, X_targ, U_targ, clock, plant_op0, plant_ops, Q, R, Qf, sat, du=None,
                  max_iter=100, warm_start=True, qp_flags=None, plant_kind=_lib.PLANT_HAMILTONIAN, device=-1,
-                 force_complex=False, exact_qp=False):
+                 force_complex=False, exact_qp=False, traceless=True, tile=False):
     """An EnsembleSession loaded with mpc_batch's arguments (everything resident in HBM, nothing run yet)."""
     x0 = np.ascontiguousarray(x0, dtype=np.complex128)
     Bn, n = x0.shape
@@ -255,7 +255,7 @@ def open_session(x0, models, dim_u, order, X_targ, U_targ, clock, plant_op0, pla
     T, ns = clock.horizon, clock.n_steps
     cols = min(X_targ.shape[-1], ns + T + 1)
     sess = EnsembleSession(Bn, n, dim_u, order, T, ns, clock.dt, sat, du, max_iter, warm_start, qp_flags, plant_kind,
-                           models.shape[0] > 1, per_plant, per_targ, cols, device=device, force_complex=force_complex,
+                           models.shape[0] > 1, per_plant, per_targ, cols, device=device, force_complex=force_complex, traceless=traceless, tile=tile,
                            measure_freq=getattr(clock, "measure_freq", 1), exact_qp=exact_qp)
     try:
         sess.load_problem(models, x0, X_targ, U_targ, Q, R, Qf, op0, ops)
@@ -267,17 +267,18 @@ def open_session(x0, models, dim_u, order, X_targ, U_targ, clock, plant_op0, pla
 
 def mpc_batch(x0, models, dim_u, order, X_targ, U_targ, clock, plant_op0, plant_ops, Q, R, Qf, sat, du=None,
               max_iter=100, warm_start=True, qp_flags=None, plant_kind=_lib.PLANT_HAMILTONIAN, device=-1,
-              force_complex=False, exact_qp=False):
+              force_complex=False, exact_qp=False, traceless=True, tile=False):
     """B independent closed loops in one launch.
     x0 [B, n]; models [B|1, n, n(1+P)]; X_targ (n, cols) / U_targ (m, cols) shared (or [B, ...] each);
     plant_op0 [B|1, k, k], plant_ops [B|1, m, k, k].  Returns a dict: xs [B, n, n_steps+1], us [B, m, n_steps]
     (entries beyond steps_done are not meaningful), exit_codes, steps_done, qp_solves [B, n_steps]."""
     sess = open_session(x0, models, dim_u, order, X_targ, U_targ, clock, plant_op0, plant_ops, Q, R, Qf, sat, du, max_iter,
-                        warm_start, qp_flags, plant_kind, device, force_complex, exact_qp)
+                        warm_start, qp_flags, plant_kind, device, force_complex, exact_qp, traceless, tile)
     try:
         sess.run(0, clock.n_steps)
         res = sess.results()
         res["path"] = sess.path()
+        res["path_detail"] = sess.path_detail()
         res["kernel_ms"] = sess.kernel_ms()[0]
         res["qp_stats"] = sess.qp_stats()
     finally:

@@ -15,9 +15,14 @@ def _bench():
 
 def test_executed_flops_and_compulsory_bytes():
     b = _bench()
-    # 27 kflop per horizon-step for the complex recursion at d=3; the real path executes a quarter
-    assert b.executed_flop_per_hstep(9, "complex") == 27e3 and b.executed_flop_per_hstep(9, "real") == 6750.0
-    assert b.executed_flop_per_hstep(16, "real") == 126e3 / 4
+    # ~3.4 k complex MACs = 27 kflop per horizon-step for the complex recursion at d=3 (order 1: P = 2); the real
+    # recursion executes a quarter of that, the traceless one (8 coordinates) 5.2 kflop
+    assert b.mac_per_hstep(9, 2, 2) == 486 + 2800 + 119
+    assert abs(b.executed_flop_per_hstep(9, 2, 2, "complex") - 27e3) < 0.3e3
+    assert b.executed_flop_per_hstep(9, 2, 2, "real") == b.executed_flop_per_hstep(9, 2, 2, "complex") / 4
+    assert b.executed_flop_per_hstep(9, 2, 2, "traceless") == 2.0 * b.mac_per_hstep(8, 2, 2) == 5176.0
+    assert b.executed_flop_per_hstep(9, 2, 2, "traceless-tile") == 5176.0
+    assert abs(b.executed_flop_per_hstep(16, 3, 3, "complex") - 126e3) < 2e3
     # config 3, real path: model 8*9*27, x0 (16+8)*9, xs 16*9*21, us 8*2*20, guess 16*9*41 + 8*2*40, codes and counts 8 + 80
     per = 8 * 9 * 27 + 24 * 9 + 16 * 9 * 21 + 8 * 2 * 20 + 16 * 9 * 41 + 8 * 2 * 40 + 8 + 80
     assert b.compulsory_bytes(65536, 9, 2, 2, 40, 20, "real") == 65536 * per
@@ -40,12 +45,12 @@ def test_counter_records_are_refused_when_stale(tmp_path, monkeypatch):
 
 
 def test_committed_counter_records_cover_every_baseline_config():
-    recs = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
+    recs = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc.json")))
     for key in ("config2_B8192_real_clip", "config3_B65536_real_clip", "config3_B65536_complex_clip", "config3_B65536_real_exact",
                 "config4_B65536_real_clip", "config5_B131072_real_clip"):
         r = recs[key]
         assert r["traced_avg_launch_ms"] > 0 and r["counters"]["SQ_INSTS_VALU_FMA_F64"] > 0
-        assert r["counters"]["SQ_INSTS_VALU_MFMA_MOPS_F64"] == 0            # no MFMA instruction in any of the kernels
+        assert r["counters"]["SQ_INSTS_VALU_MFMA_MOPS_F64"] == 0            # no MFMA instruction in any of the default kernels
         # the HIP-event time of bench.py and rocprofv3's kernel-trace average of the same run agree
         assert abs(r["hip_event_launch_ms_same_run"] - r["traced_avg_launch_ms"]) <= 0.02 * r["traced_avg_launch_ms"]
 

@@ -18,7 +18,7 @@ for s in $all; do
   if echo " $shapes " | grep -q " $s "; then
     IFS=_ read nx nu ord <<< "$s"
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-command-line-argument \
-        -DM4Q_NX=$nx -DM4Q_NU=$nu -DM4Q_ORDER=$ord "$@" -c $src/m4q_kernels.hip -o $out/kernels_$s.o &
+        -DM4Q_DEV -DM4Q_NX=$nx -DM4Q_NU=$nu -DM4Q_ORDER=$ord "$@" -c $src/m4q_kernels.hip -o $out/kernels_$s.o &
     pids="$pids $!"
     objs="$objs $out/kernels_$s.o"
   else
