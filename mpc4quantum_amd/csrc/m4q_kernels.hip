@@ -146,6 +146,9 @@ struct RowStash {
 // TL: the state lives in the NX - 1 traceless coordinates (S = double only; m4q_mpc.h).  NS = dimension of the recursion;
 // the I/O side (xs, the SQP-guess checkpoint, the plant) stays NX complex numbers per node.
 // TILE: the two sweeps of the clipped solve run on fp64 matrix-core tiles (m4q_tile.h) instead of DPP rows.
+#ifndef M4Q_WAVES_EXACT
+#define M4Q_WAVES_EXACT(S) WavesFor<S>::value
+#endif
 #ifndef M4Q_WAVES_TILE
 #define M4Q_WAVES_TILE 2
 #endif
@@ -162,7 +165,7 @@ struct RowStash {
 #define M4Q_PHASE_DECL PhaseClock pc;
 #define M4Q_PHASE_MARK(i) pc.mark(i);
 template <class S, int PLANT, bool EXACT, bool TL = false, bool TILE = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_WAVES_TILE : WavesFor<S>::value, 8))) void mpc_kernel(MpcArgs) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_WAVES_TILE : EXACT ? M4Q_WAVES_EXACT(S) : WavesFor<S>::value, 8))) void mpc_kernel(MpcArgs) {
   static_assert(!TL || (sizeof(S) == sizeof(double) && SQUARE), "the traceless path is a real path of a d x d density matrix");
   static_assert(!TILE || (TL && !EXACT), "tile sweeps: clipped solve on the traceless real coordinates");
   constexpr int NS = TL ? NX - 1 : NX;
@@ -531,7 +534,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
         // rows starting a solve: the current SQP guess (the shifted previous solution on warm steps: nearly the right
         // working set), clipped into the box and rolled out through the linearised model.  The linearisation point
         // (Xg, Ug) stays untouched until the solve is over.
-        const bool start = running && !qp.busy;
+        const bool start = running && !qp.busy();
         double J0 = 0.0;
         M4Q_PHASE_MARK(3)
         if (__any(start)) {
@@ -542,16 +545,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
         bool bad_start = false;
         if (start) {
           qp.begin(J0);
-          if (!finite_d(J0)) { qp.busy = false; bad_start = true; }
+          if (!finite_d(J0)) { qp.busy() = false; bad_start = true; }
         }
-        if (__any(qp.busy)) ++qp_passes;
+        if (__any(qp.busy())) ++qp_passes;
         const bool ended = box_qp_iterate<S, NS, NU>(prov, fresh(T), x_cur, win, cost, flags, gains, pin, Xo, Uo, Xalt, Ualt, qp, j, jj, lane_ok, &pc);
         solved = running && (ended || bad_start);
         capped = solved && !bad_start && qp.stats.end_cap > 0;
         chk = qp.Jk;
         GView Xs = Xo, Us = Uo;
-        Xs.off = qp.cur_is_a ? Xo.off : Xalt.off;
-        Us.off = qp.cur_is_a ? Uo.off : Ualt.off;
+        Xs.off = qp.cur_is_a() ? Xo.off : Xalt.off;
+        Us.off = qp.cur_is_a() ? Uo.off : Ualt.off;
         if (solved && jj == 0) {
           M4Q_GLOBAL unsigned long long* cnt = (M4Q_GLOBAL unsigned long long*)kargs()->queue;
           __hip_atomic_fetch_add(cnt + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -598,7 +601,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
             }
           };
           if (use_ls) {
-            if (!qp.cur_is_a) {
+            if (!qp.cur_is_a()) {
               copy_x(Xo, Xs, 0);
               copy_u(Uo, Us, 0);
             }
@@ -942,12 +945,12 @@ __global__ __launch_bounds__(64) M4Q_OCC void qp_kernel(QpArgs a) {
       for (int k = 0; k < NU; ++k) { pin.lo0[k] = lo0[k]; pin.hi0[k] = hi0[k]; }
       BoxQpRow row;
       if (valid) row.begin(obj);
-      while (__any(row.busy)) box_qp_iterate<cplx, NX, NU>(prov, T, x0, win, cost, a.flags, gains, pin, Xa, Ua, Xb, Ub, row, j, jj, L.lane_ok);
+      while (__any(row.busy())) box_qp_iterate<cplx, NX, NU>(prov, T, x0, win, cost, a.flags, gains, pin, Xa, Ua, Xb, Ub, row, j, jj, L.lane_ok);
       obj_out = row.Jk;
       const QpStats& stats = row.stats;
       GView Xs = Xa, Us = Ua;
-      Xs.off = row.cur_is_a ? Xa.off : Xb.off;
-      Us.off = row.cur_is_a ? Ua.off : Ub.off;
+      Xs.off = row.cur_is_a() ? Xa.off : Xb.off;
+      Us.off = row.cur_is_a() ? Ua.off : Ub.off;
       if (st) {
         for (int t = 0; t <= T; ++t) Xo.st<cplx>(t * NX + j, Xs.ld<cplx>(t * NX + j));
         if (j == 0)

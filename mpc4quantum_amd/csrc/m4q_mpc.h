@@ -1326,20 +1326,33 @@ __device__ __forceinline__ double rollout_open(const Prov& prov, int T, S x0, co
 // Per-row state of a box-QP solve in progress (uniform inside a row).  The buffers: two trajectory pairs
 // (Xa, Ua) / (Xb, Ub) - which must share their wave-uniform bases, rows pick theirs by lane offset - ping-pong;
 // `cur_is_a` tells which one holds the iterate (and, once `busy` drops, the answer).
+// The row's booleans live as bits of ONE integer (a VGPR): a bool that differs between rows is a 64-bit lane mask in an SGPR pair, and
+// the dozen of them that are live across the sweeps of an iteration were most of what the exact kernels spilled (60-84 SGPRs per
+// instantiation into VGPR lanes).  Read where needed (v_and + v_cmp), and made opaque after every sweep (settle) so that the
+// comparisons are not hoisted back across it.
+template <int BIT>
+struct RowBit {
+  int& w;
+  __device__ __forceinline__ operator bool() const { return (w & BIT) != 0; }
+  __device__ __forceinline__ RowBit& operator=(bool v) { w = v ? (w | BIT) : (w & ~BIT); return *this; }
+};
 struct BoxQpRow {
-  bool busy = false;
-  bool need_adj = true;    // the working set has to be (re-)derived from the gradient at the iterate
-  bool face_min = false;   // the iterate minimises J over the face of the working set in `stat`
-  bool cur_is_a = true;
+  int w = 2 | 8;
+  __device__ __forceinline__ RowBit<1> busy() { return RowBit<1>{w}; }
+  __device__ __forceinline__ RowBit<2> need_adj() { return RowBit<2>{w}; }    // the working set has to be (re-)derived from the gradient at the iterate
+  __device__ __forceinline__ RowBit<4> face_min() { return RowBit<4>{w}; }    // the iterate minimises J over the face of the working set in `stat`
+  __device__ __forceinline__ RowBit<8> cur_is_a() { return RowBit<8>{w}; }
+  // scratch bits of box_qp_iterate (meaningless between calls)
+  __device__ __forceinline__ RowBit<16> was_busy() { return RowBit<16>{w}; }
+  __device__ __forceinline__ RowBit<32> going() { return RowBit<32>{w}; }
+  __device__ __forceinline__ RowBit<64> moved() { return RowBit<64>{w}; }
+  __device__ __forceinline__ void settle() { asm volatile("" : "+v"(w)); }
   int stalls = 0, iters = 0;
   double Jk = 0.0;
   QpStats stats;
   // (Xa, Ua) hold a feasible point with its linearised trajectory, J its objective
   __device__ __forceinline__ void begin(double J) {
-    busy = true;
-    need_adj = true;
-    face_min = false;
-    cur_is_a = true;
+    w = 1 | 2 | 8;
     stalls = 0;
     iters = 0;
     Jk = J;
@@ -1347,15 +1360,19 @@ struct BoxQpRow {
   }
 };
 
-// One iteration of the exact solve for the rows of the wavefront that have one in progress (r.busy).  Returns true for
-// the rows whose solve ended in this call: r.Jk is then the objective of the answer, r.cur_is_a says where it is.
+// One iteration of the exact solve for the rows of the wavefront that have one in progress (r.busy()).  Returns true for
+// the rows whose solve ended in this call: r.Jk is then the objective of the answer, r.cur_is_a() says where it is.
 template <class S, int NX, int NU, class Prov>
 __device__ __forceinline__ bool box_qp_iterate(const Prov& prov, int T, S x0, const Window& win, const CostRef<S>& cost, int flags,
                                                const GView& gains, PinCtx<NU>& pin, GView Xa, GView Ua, GView Xb, GView Ub,
                                                BoxQpRow& r, int j, int jj, bool lane_ok, PhaseClock* pc = nullptr) {
   PhaseClock none;
   PhaseClock& clk = pc ? *pc : none;
-  const bool was_busy = r.busy;
+  r.was_busy() = r.busy();
+  int jl = jj;                                       // (lane_ok is recomputed from this after every sweep, for the same reason)
+  auto settle = [&]() __attribute__((always_inline)) { r.settle(); asm volatile("" : "+v"(jl)); };
+  auto ok = [&]() __attribute__((always_inline)) { return jl < NX; };
+  (void)lane_ok;
   // (every sweep of the iteration gets the horizon through an opaque copy: loop bounds and unroll-remainder predicates derived
   //  from it then live inside that sweep instead of across the whole iteration, where they were spilled to VGPR lanes)
   auto Tf = [&]() __attribute__((always_inline)) { int v = T; asm volatile("" : "+s"(v)); return v; };
@@ -1366,16 +1383,17 @@ __device__ __forceinline__ bool box_qp_iterate(const Prov& prov, int T, S x0, co
   // KKT verdict of a face minimiser normally comes from the policy rollout itself (RolloutInfo::nbad), so a solve still ends
   // in the pass of its last Riccati sweep.  (Round 3 until then: a second pass at the end of the call, 27 % of the launch.)
   auto derive_working_sets = [&]() __attribute__((always_inline)) {
-    const bool adj = r.busy && r.need_adj;
-    if (__any(adj)) {
-      pin.derive = adj;
+    if (__any(r.busy() && r.need_adj())) {
+      pin.derive = r.busy() && r.need_adj();
       pin.Xk = Xa; pin.Uk = Ua;
-      pin.Xk.off = r.cur_is_a ? Xa.off : Xb.off;
-      pin.Uk.off = r.cur_is_a ? Ua.off : Ub.off;
-      adjoint_pass<S, NX, NU>(prov, Tf(), win, cost, pin, j, adj && lane_ok);
+      pin.Xk.off = r.cur_is_a() ? Xa.off : Xb.off;
+      pin.Uk.off = r.cur_is_a() ? Ua.off : Ub.off;
+      adjoint_pass<S, NX, NU>(prov, Tf(), win, cost, pin, j, r.busy() && r.need_adj() && ok());
       wave_sync();
-      if (adj && r.face_min && pin.nchg == 0) { r.busy = false; ++r.stats.end_kkt; }
-      if (adj) { r.need_adj = false; r.face_min = false; }
+      settle();
+      const bool adj = r.busy() && r.need_adj();
+      if (adj && r.face_min() && pin.nchg == 0) { r.busy() = false; ++r.stats.end_kkt; }
+      if (adj) { r.need_adj() = false; r.face_min() = false; }
     }
   };
   clk.mark(15);
@@ -1383,50 +1401,57 @@ __device__ __forceinline__ bool box_qp_iterate(const Prov& prov, int T, S x0, co
   clk.mark(1);
   // per-row source / destination: same wave-uniform bases, lane offsets swapped
   GView Xk = Xa, Uk = Ua, Xc = Xb, Uc = Ub;
-  Xk.off = r.cur_is_a ? Xa.off : Xb.off;
-  Uk.off = r.cur_is_a ? Ua.off : Ub.off;
-  Xc.off = r.cur_is_a ? Xb.off : Xa.off;
-  Uc.off = r.cur_is_a ? Ub.off : Ua.off;
-  if (__any(r.busy)) {
-    const bool going = r.busy;
-    if (going) ++r.iters;
-    riccati_backward<S, NX, NU, Prov, true>(prov, Tf(), win, cost, flags, gains, j, going && lane_ok, &pin);
+  Xk.off = r.cur_is_a() ? Xa.off : Xb.off;
+  Uk.off = r.cur_is_a() ? Ua.off : Ub.off;
+  Xc.off = r.cur_is_a() ? Xb.off : Xa.off;
+  Uc.off = r.cur_is_a() ? Ub.off : Ua.off;
+  if (__any(r.busy())) {
+    r.going() = r.busy();
+    r.moved() = false;
+    if (r.going()) ++r.iters;
+    riccati_backward<S, NX, NU, Prov, true>(prov, Tf(), win, cost, flags, gains, j, r.going() && ok(), &pin);
     wave_sync();
+    settle();
     clk.mark(10);
     RolloutInfo ri;
-    const double Jc = rollout_policy<S, NX, NU>(prov, Tf(), x0, win, cost, gains, pin, Uk, true, Xc, Uc, j, going && lane_ok, ri);
+    const double Jc = rollout_policy<S, NX, NU>(prov, Tf(), x0, win, cost, gains, pin, Uk, true, Xc, Uc, j, r.going() && ok(), ri);
     wave_sync();
+    settle();
     clk.mark(11);
+    const bool going = r.going();
     if (going) ++r.stats.sweeps;
     bool moved = false;
     if (going && !(ri.dmax > 1e-13 * box.sat)) {
       // the policy reproduces the iterate: it is the minimiser of its face (or NaN)
-      if (!(ri.dmax == ri.dmax) || ++r.stalls > 1) { r.busy = false; ++r.stats.end_precision; }
-      else if (!ri.outside && ri.nbad == 0) { r.busy = false; ++r.stats.end_kkt; }      // face minimiser, multipliers of the right sign
-      r.face_min = true;
-      r.need_adj = true;
+      if (!(ri.dmax == ri.dmax) || ++r.stalls > 1) { r.busy() = false; ++r.stats.end_precision; }
+      else if (!ri.outside && ri.nbad == 0) { r.busy() = false; ++r.stats.end_kkt; }      // face minimiser, multipliers of the right sign
+      r.face_min() = true;
+      r.need_adj() = true;
     } else if (going && (Jc < r.Jk || (!ri.outside && Jc <= r.Jk + 1e-12 * fabs(r.Jk) && r.stalls < 2))) {
       // (a face minimiser is taken even without a visible decrease: near the optimum J is flat to working precision
       //  long before the controls are, and the Newton point is the more accurate of the two)
       r.stalls = Jc < r.Jk ? 0 : r.stalls + 1;
       moved = true;
       r.Jk = Jc;
-      r.face_min = !ri.outside;
-      r.need_adj = true;
+      r.face_min() = !ri.outside;
+      r.need_adj() = true;
       // nothing clipped: the new iterate minimises J over the face; if every pinned control's multiplier has the right sign it
       // is the optimum (KKT) - known from the rollout itself.  Otherwise the working set is re-derived from the gradient.
-      if (!ri.outside && ri.nbad == 0) { r.busy = false; ++r.stats.end_kkt; }
+      if (!ri.outside && ri.nbad == 0) { r.busy() = false; ++r.stats.end_kkt; }
     } else if (going && !ri.outside) {
-      r.busy = false;                                          // face minimiser without decrease: working precision
+      r.busy() = false;                                          // face minimiser without decrease: working precision
       ++r.stats.end_precision;
     }
     // classical step for the rows whose clipped rollout did not decrease J
-    const bool ratio = r.busy && going && !moved && !r.face_min;
-    if (__any(ratio)) {
+    r.moved() = moved;
+    if (__any(r.busy() && r.going() && !r.moved() && !r.face_min())) {
       RolloutInfo rn;
-      const double Jn = rollout_policy<S, NX, NU>(prov, Tf(), x0, win, cost, gains, pin, Uk, false, Xc, Uc, j, ratio && lane_ok, rn);
+      const double Jn = rollout_policy<S, NX, NU>(prov, Tf(), x0, win, cost, gains, pin, Uk, false, Xc, Uc, j,
+                                                  r.busy() && r.going() && !r.moved() && !r.face_min() && ok(), rn);
       wave_sync();
+      settle();
       clk.mark(12);
+      const bool ratio = r.busy() && r.going() && !r.moved() && !r.face_min();
       if (ratio) {
         ++r.stats.ratio_steps;
         const double al = rn.alpha;
@@ -1463,18 +1488,18 @@ __device__ __forceinline__ bool box_qp_iterate(const Prov& prov, int T, S x0, co
         }
         const double q = 1.0 - al;
         r.Jk = fma(r.Jk - Jn, q * q, Jn);                      // J along the segment to the face minimiser
-        moved = true;
+        r.moved() = true;
         // al == 0 (degenerate): free controls sit on the bound the step wants to cross; they are pinned now, nothing moved
         r.stalls = al > 0.0 ? 0 : r.stalls + 1;
-        if (r.stalls > 2 * NU * T) { r.busy = false; ++r.stats.end_cap; }
+        if (r.stalls > 2 * NU * T) { r.busy() = false; ++r.stats.end_cap; }
       }
     }
     clk.mark(13);
-    if (going && moved) r.cur_is_a = !r.cur_is_a;
-    if (r.busy && r.iters >= 100 + 2 * NU * T) { r.busy = false; ++r.stats.end_cap; }   // (the path adds at least one control per step)
+    if (r.going() && r.moved()) r.cur_is_a() = !r.cur_is_a();
+    if (r.busy() && r.iters >= 100 + 2 * NU * T) { r.busy() = false; ++r.stats.end_cap; }   // (the path adds at least one control per step)
     wave_sync();
   }
-  return was_busy && !r.busy;
+  return r.was_busy() && !r.busy();
 }
 
 // ---------------------------------------------------------------------------------------------
