@@ -3,7 +3,8 @@
 scratch (spill) instructions, LDS reads, waits and register moves inside it.
 
     python3 tools/hot_loops.py 9_2_1 'mpc_kernelIdLi1ELb0'        # shape, substring of the mangled kernel name
-Reads mpc4quantum_amd/csrc/build/kernels_<shape>.o (runs on the CPU box: disassembly only)."""
+Reads mpc4quantum_amd/csrc/build/kernels_<shape>.o, or the object file given as fourth argument (third: DPP-FMA threshold, default 100) (runs on the CPU box:
+disassembly only)."""
 import re
 import subprocess
 import sys
@@ -14,7 +15,7 @@ B = "/opt/rocm/lib/llvm/bin/"
 
 def main():
     shape, flt = sys.argv[1], sys.argv[2]
-    obj = "mpc4quantum_amd/csrc/build/kernels_%s.o" % shape
+    obj = sys.argv[4] if len(sys.argv) > 4 else "mpc4quantum_amd/csrc/build/kernels_%s.o" % shape
     with tempfile.TemporaryDirectory() as tmp:
         subprocess.check_call([B + "llvm-objcopy", "--dump-section", ".hip_fatbin=%s/fat.bin" % tmp, obj])
         subprocess.check_call([B + "clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
