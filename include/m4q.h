@@ -68,9 +68,10 @@ extern "C" {
  * such a session on the d*d-coordinate real path. */
 #define M4Q_OPT_NO_TRACELESS 2
 /* Experimental: a traceless session with a constant target over the horizon window runs the two sweeps of the clipped solve
- * on fp64 matrix-core tiles (v_mfma_f64_4x4x4_4b_f64, csrc/m4q_tile.h) instead of DPP rows.  Same results to rounding; on
- * MI355X it is SLOWER than the DPP sweeps today (config 3: 54 against 47 ms - the tile rollout is bound by workspace latency,
- * profiles/r03_tile_log.txt), so it is off unless this bit (or M4Q_TILE=1 in the environment) asks for it. */
+ * on fp64 matrix-core tiles (v_mfma_f64_4x4x4_4b_f64, csrc/m4q_tile.h) instead of DPP rows - as built now the backward
+ * sweep on tiles, the rollout on DPP rows.  Same results to rounding; on MI355X it is not faster than the DPP sweeps (config 3:
+ * 41.9 against 41.5 ms; both sweeps on tiles 55 ms - dependent MFMA latency, profiles/r03_tile_log.txt), so it is off unless
+ * this bit (or M4Q_TILE=1 in the environment) asks for it. */
 #define M4Q_OPT_TILE 4
 
 /* exit codes per instance (mpc.py:130,195,202,291): 0 normal, 1 exit_condition (host side),
@@ -127,7 +128,11 @@ M4Q_API int m4q_linearize_batch(int32_t B, int32_t dim_x, int32_t dim_u, int32_t
  * x_init [B][n] c, X_bm [B|1][T+1][n] c, U_bm [B|1][T][m] r, Q_ls [T+1][n][n] c, R_ls [T][m][m] c,
  * A_ls [B][T][n][n] c, B_ls [B][T][n][m] c, Delta_ls [B][T][n] c (NULL = zero),
  * u_prev [B][m] r (NULL = no band) -> X_opt [B][T+1][n] c, U_opt [B][T][m] r, cost [B] r,
- * gains [B][T][n+1][m] c (NULL to skip; gains[b][t][col][k] = Gains[t][k][col] of lqr.py:61) */
+ * gains [B][T][n+1][m] c (NULL to skip; gains[b][t][col][k] = Gains[t][k][col] of lqr.py:61).
+ * With M4Q_QP_EXACT_BOX the gains are those of the final active-set iteration: a control that is free at the optimum has its
+ * feedback row; a control PINNED on a bound at (t, k) has, in its slot, the affine form of its multiplier along the optimal
+ * trajectory (row . (x_t - xbar_t) + const = dJ/du_tk, sign opposite to the side it is pinned on) - not the [0 | u - ubar] row
+ * a constant control would have. */
 M4Q_API int m4q_quad_program_batch(int32_t B, int32_t dim_x, int32_t dim_u, int32_t T, int32_t qp_flags, double sat, double du,
                            const double* x_init, const double* X_bm, const double* U_bm, int32_t bm_per_instance,
                            const double* Q_ls, const double* R_ls, const double* A_ls, const double* B_ls,

@@ -894,7 +894,8 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
   // variant build ran a staged probe (tests/probes/two_index_probe.py: one member / one step up to the faulting case) and 143 GPU
   // tests without a fault, at the one-index build's speed (117.3 against 117.0 ms, config 4 complex, 16,384 members):
   // profiles/r02_two_index_complex_d4_fault.log.  The fault is therefore not explained - a property of one build, not reproduced by
-  // the next - and the form stays off because it brings nothing.
+  // the next - and the form stays off because it brings nothing.  Round 3: rebuilt once more from that round's source, probe and
+  // GPU tests under a 10 s watchdog, green again.
 #ifndef M4Q_TWO_INDEX_COMPLEX
 #define M4Q_TWO_INDEX_COMPLEX 0
 #endif
@@ -1140,9 +1141,11 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
 //      on a bound the Newton step wants to cross, common with these stiff Hessians) they would otherwise come one per
 //      sweep.  J(a) = J_N + (J^k - J_N)(1 - a)^2 along the segment, so this always decreases J and needs no
 //      evaluation; trajectories blend linearly;
-//   4. W is re-derived from the gradient (adjoint recursion, run inside the next Riccati sweep: a control on a bound
+//   4. W is re-derived from the gradient (adjoint_pass, once per call of box_qp_iterate: a control on a bound
 //      with the gradient pushing outward is pinned, all others free) after 2; kept, plus the blocking controls, after 3.
-// Converged when a face minimiser is followed by an unchanged working set (multipliers of the right sign = KKT).
+// Converged when a face minimiser has multipliers of the right sign on every pinned control (KKT): read off the policy rollout
+// (RolloutInfo::nbad, from the multiplier rows riccati_backward<PINNED> stores for pinned controls), or - for a multiplier the two
+// computations put on different sides of zero - when the re-derived working set comes back unchanged.
 // J decreases strictly from iterate to iterate, so no face is visited twice.
 // ---------------------------------------------------------------------------------------------
 struct QpStats {   // per row, counted by the caller
