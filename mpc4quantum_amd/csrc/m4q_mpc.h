@@ -637,6 +637,9 @@ struct PinCtx {
   bool derive = false;
   GView Xk, Uk;
   int nchg = 0;
+  // rollout_policy (per row, `pdas`): the primal-dual update of the working set, in place: a free control that the unclipped policy
+  // puts beyond a bound is pinned there, a pinned one whose multiplier has the wrong sign is let go (RolloutInfo::nchg counts).
+  bool pdas = false;
   // pinned value of control k at horizon index t, or free
   __device__ __forceinline__ bool pinned(int t, int k, double& value) const {
     const double st = stat.ld<double>(t * NU + k);
@@ -1160,6 +1163,8 @@ struct RolloutInfo {
   double alpha;      // ratio test: largest step along u^k -> u that stays in the box (<= 1)
   int nbad;          // pinned controls whose multiplier along this rollout has the wrong sign (meaningful when !outside: the
                      // rollout is then the minimiser over its face, and nbad == 0 is the KKT test)
+  int nchg;          // PinCtx::pdas: entries of the working set this rollout changed (0: the unclipped rollout is feasible and
+                     // every multiplier has the right sign - the optimum)
 };
 
 // closed-loop rollout of the policy in `gains` (pinned controls sit on their bound), with (clip) or without clipping
@@ -1174,6 +1179,7 @@ __device__ __forceinline__ double rollout_policy(const Prov& prov, int T, S x0, 
   info.outside = false;
   info.alpha = 1.0;
   info.nbad = 0;
+  info.nchg = 0;
   double cx = 0.0, cu = 0.0;
   // operands of horizon index t+1 are fetched while index t computes (two sets swapping roles, as in rollout_forward): the
   // step is a short dependent chain and every operand comes from the workspace, i.e. from beyond the L2
@@ -1222,8 +1228,16 @@ __device__ __forceinline__ double rollout_policy(const Prov& prov, int T, S x0, 
       un[k] = fixd ? pv : v;
       // pinned at the upper bound wants a gradient pushing up (mu < 0), at the lower one mu > 0 - the rule of adjoint_pass;
       // a degenerate interval is pinned whatever the sign
-      if (fixd && hi - lo > 2e-12 * pin.box.sat && !(cur.st[k] > 0.0 ? lin < 0.0 : lin > 0.0)) ++info.nbad;
+      const bool wrong = fixd && hi - lo > 2e-12 * pin.box.sat && !(cur.st[k] > 0.0 ? lin < 0.0 : lin > 0.0);
+      if (wrong) ++info.nbad;
       const bool above = un[k] > hi, below = un[k] < lo;
+      if (pin.pdas) {
+        const double ns = fixd ? (wrong ? 0.0 : cur.st[k]) : (above ? 1.0 : below ? -1.0 : 0.0);
+        if (ns != cur.st[k]) {
+          ++info.nchg;
+          if (store_ok && j == 0) pin.stat.template st<double>(t * NU + k, ns);
+        }
+      }
       if (above || below) {
         info.outside = true;
         info.alpha = fmin(info.alpha, ((above ? hi : lo) - uk) / (un[k] - uk));        // u^k is feasible: 0 <= a < 1
@@ -1349,7 +1363,12 @@ struct BoxQpRow {
   __device__ __forceinline__ RowBit<16> was_busy() { return RowBit<16>{w}; }
   __device__ __forceinline__ RowBit<32> going() { return RowBit<32>{w}; }
   __device__ __forceinline__ RowBit<64> moved() { return RowBit<64>{w}; }
+  __device__ __forceinline__ RowBit<512> was_pdas() { return RowBit<512>{w}; }
+  // second phase of a solve (see box_qp_iterate): primal-dual active-set iterations on the working set alone
+  __device__ __forceinline__ RowBit<128> pdas() { return RowBit<128>{w}; }
+  __device__ __forceinline__ RowBit<256> pdas_done() { return RowBit<256>{w}; }   // ... was entered once in this solve
   __device__ __forceinline__ void settle() { asm volatile("" : "+v"(w)); }
+  int pdas_its = 0;
   int stalls = 0, iters = 0;
   double Jk = 0.0;
   QpStats stats;
@@ -1362,6 +1381,15 @@ struct BoxQpRow {
     stats = QpStats();
   }
 };
+
+// Iterations a solve may spend in its primal-dual phase before it falls back (CPU prototypes tests/probes/pdas_proto.py,
+// pdas_switch_proto.py: config 3's hard solves - the first warm steps, whose shifted guess is poor - need up to 22 on the members
+// tried; config 4's often cycle, and pay for the try).  Measured on config 3, 65,536 members: cap 16 298 ms, 24 278, 40 254, 64 263,
+// 100 272 (profiles/r03_exact_qp_log.txt).
+#ifndef M4Q_PDAS_CAP
+#define M4Q_PDAS_CAP 40
+#endif
+constexpr int PDAS_CAP = M4Q_PDAS_CAP;
 
 // One iteration of the exact solve for the rows of the wavefront that have one in progress (r.busy()).  Returns true for
 // the rows whose solve ended in this call: r.Jk is then the objective of the answer, r.cur_is_a() says where it is.
@@ -1411,20 +1439,39 @@ __device__ __forceinline__ bool box_qp_iterate(const Prov& prov, int T, S x0, co
   if (__any(r.busy())) {
     r.going() = r.busy();
     r.moved() = false;
+    r.was_pdas() = r.pdas();
     if (r.going()) ++r.iters;
     riccati_backward<S, NX, NU, Prov, true>(prov, Tf(), win, cost, flags, gains, j, r.going() && ok(), &pin);
     wave_sync();
     settle();
     clk.mark(10);
     RolloutInfo ri;
-    const double Jc = rollout_policy<S, NX, NU>(prov, Tf(), x0, win, cost, gains, pin, Uk, true, Xc, Uc, j, r.going() && ok(), ri);
+    // (rows in their primal-dual phase: the UNCLIPPED rollout of the face minimiser, which updates the working set as it goes)
+    pin.pdas = r.going() && r.pdas();
+    const double Jc = rollout_policy<S, NX, NU>(prov, Tf(), x0, win, cost, gains, pin, Uk, !(r.going() && r.pdas()), Xc, Uc, j,
+                                                r.going() && ok(), ri);
+    pin.pdas = false;
     wave_sync();
     settle();
     clk.mark(11);
     const bool going = r.going();
     if (going) ++r.stats.sweeps;
     bool moved = false;
-    if (going && !(ri.dmax > 1e-13 * box.sat)) {
+    if (going && r.pdas()) {
+      // primal-dual phase: nothing changed = the unclipped face minimiser is feasible with multipliers of the right sign: the optimum
+      if (ri.nchg == 0) {
+        moved = true;
+        r.Jk = Jc;
+        r.busy() = false;
+        ++r.stats.end_kkt;
+      } else if (++r.pdas_its >= PDAS_CAP) {
+        // (a cycle or a slow crawl: back to the iteration that cannot cycle, from the feasible iterate, which has not moved.  Detecting
+        //  cycles of period <= 4 by a signature of the set bought nothing: 258 against 254 ms - the solves that give up crawl)
+        r.pdas() = false;
+        r.need_adj() = true;
+        r.face_min() = false;
+      }
+    } else if (going && !(ri.dmax > 1e-13 * box.sat)) {
       // the policy reproduces the iterate: it is the minimiser of its face (or NaN)
       if (!(ri.dmax == ri.dmax) || ++r.stalls > 1) { r.busy() = false; ++r.stats.end_precision; }
       else if (!ri.outside && ri.nbad == 0) { r.busy() = false; ++r.stats.end_kkt; }      // face minimiser, multipliers of the right sign
@@ -1447,14 +1494,33 @@ __device__ __forceinline__ bool box_qp_iterate(const Prov& prov, int T, S x0, co
     }
     // classical step for the rows whose clipped rollout did not decrease J
     r.moved() = moved;
-    if (__any(r.busy() && r.going() && !r.moved() && !r.face_min())) {
+    // rows whose clipped trial did not lower J.  The first time in a solve: the solve enters its primal-dual phase - the unclipped
+    // rollout of the same policy makes the first update of the working set; the iterate stays.  After that phase (it gave up):
+    // the classical ratio step.
+    if (__any(r.busy() && r.going() && !r.moved() && !r.face_min() && !r.was_pdas())) {
       RolloutInfo rn;
+      pin.pdas = r.busy() && r.going() && !r.moved() && !r.face_min() && !r.was_pdas() && !r.pdas_done();
       const double Jn = rollout_policy<S, NX, NU>(prov, Tf(), x0, win, cost, gains, pin, Uk, false, Xc, Uc, j,
-                                                  r.busy() && r.going() && !r.moved() && !r.face_min() && ok(), rn);
+                                                  r.busy() && r.going() && !r.moved() && !r.face_min() && !r.was_pdas() && ok(), rn);
+      pin.pdas = false;
       wave_sync();
       settle();
       clk.mark(12);
-      const bool ratio = r.busy() && r.going() && !r.moved() && !r.face_min();
+      const bool second = r.busy() && r.going() && !r.moved() && !r.face_min() && !r.was_pdas();
+      const bool enter = second && !r.pdas_done();
+      if (enter) {
+        r.pdas_done() = true;
+        if (rn.nchg == 0) {                                      // (cannot happen after a clipped trial; if it does, this is the optimum)
+          r.moved() = true;
+          r.Jk = Jn;
+          r.busy() = false;
+          ++r.stats.end_kkt;
+        } else {
+          r.pdas() = true;
+          r.pdas_its = 1;
+        }
+      }
+      const bool ratio = second && !enter;
       if (ratio) {
         ++r.stats.ratio_steps;
         const double al = rn.alpha;
