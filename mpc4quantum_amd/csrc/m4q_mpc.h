@@ -1368,6 +1368,8 @@ struct BoxQpRow {
   __device__ __forceinline__ RowBit<128> pdas() { return RowBit<128>{w}; }
   __device__ __forceinline__ RowBit<256> pdas_done() { return RowBit<256>{w}; }   // ... was entered once in this solve
   __device__ __forceinline__ void settle() { asm volatile("" : "+v"(w)); }
+  // several bits at once: one v_and + one v_cmp instead of a lane mask per bit
+  __device__ __forceinline__ bool is(int mask, int pattern) const { return (w & mask) == pattern; }
   int pdas_its = 0;
   int stalls = 0, iters = 0;
   double Jk = 0.0;
@@ -1447,8 +1449,8 @@ __device__ __forceinline__ bool box_qp_iterate(const Prov& prov, int T, S x0, co
     clk.mark(10);
     RolloutInfo ri;
     // (rows in their primal-dual phase: the UNCLIPPED rollout of the face minimiser, which updates the working set as it goes)
-    pin.pdas = r.going() && r.pdas();
-    const double Jc = rollout_policy<S, NX, NU>(prov, Tf(), x0, win, cost, gains, pin, Uk, !(r.going() && r.pdas()), Xc, Uc, j,
+    pin.pdas = r.is(32 | 128, 32 | 128);
+    const double Jc = rollout_policy<S, NX, NU>(prov, Tf(), x0, win, cost, gains, pin, Uk, !r.is(32 | 128, 32 | 128), Xc, Uc, j,
                                                 r.going() && ok(), ri);
     pin.pdas = false;
     wave_sync();
@@ -1497,16 +1499,16 @@ __device__ __forceinline__ bool box_qp_iterate(const Prov& prov, int T, S x0, co
     // rows whose clipped trial did not lower J.  The first time in a solve: the solve enters its primal-dual phase - the unclipped
     // rollout of the same policy makes the first update of the working set; the iterate stays.  After that phase (it gave up):
     // the classical ratio step.
-    if (__any(r.busy() && r.going() && !r.moved() && !r.face_min() && !r.was_pdas())) {
+    constexpr int SECOND = 1 | 32 | 64 | 4 | 512;                // busy, going, !moved, !face_min, !was_pdas
+    if (__any(r.is(SECOND, 1 | 32))) {
       RolloutInfo rn;
-      pin.pdas = r.busy() && r.going() && !r.moved() && !r.face_min() && !r.was_pdas() && !r.pdas_done();
-      const double Jn = rollout_policy<S, NX, NU>(prov, Tf(), x0, win, cost, gains, pin, Uk, false, Xc, Uc, j,
-                                                  r.busy() && r.going() && !r.moved() && !r.face_min() && !r.was_pdas() && ok(), rn);
+      pin.pdas = r.is(SECOND | 256, 1 | 32);                     // ... and the primal-dual phase not entered yet
+      const double Jn = rollout_policy<S, NX, NU>(prov, Tf(), x0, win, cost, gains, pin, Uk, false, Xc, Uc, j, r.is(SECOND, 1 | 32) && ok(), rn);
       pin.pdas = false;
       wave_sync();
       settle();
       clk.mark(12);
-      const bool second = r.busy() && r.going() && !r.moved() && !r.face_min() && !r.was_pdas();
+      const bool second = r.is(SECOND, 1 | 32);
       const bool enter = second && !r.pdas_done();
       if (enter) {
         r.pdas_done() = true;

@@ -129,24 +129,25 @@ def solve(H, f, c, lo, hi, u0, m, mode, PCAP=40):
         Jk = J(u)
     return u, sweeps, ratios, pd, adj, "cap"
 
-cfg, order, members = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
-ap.capture_loop(cfg, order, members)
-for mode in ("grad", "nograd"):
-    tot = {}; S = R = P = A = 0; worst = 0
-    for q in ap.CAPTURE:
-        x_init, X_bm, U_bm, Q_ls, R_ls, A_ls, B_ls, D_ls = q["args"]
-        m, T = U_bm.shape
-        if "H" not in q:
-            q["H"], q["f"], q["c"] = ap.condense(x_init, np.asarray(X_bm, dtype=complex), np.asarray(U_bm, dtype=float), Q_ls, R_ls, A_ls, B_ls, D_ls)
-        H, f, c = q["H"], q["f"], q["c"]
-        lo = -q["sat"] * np.ones(T * m); hi = q["sat"] * np.ones(T * m)
-        if q["du"] is not None and q["u_prev"] is not None:
-            up = np.reshape(q["u_prev"], -1).real
-            lo[:m] = np.maximum(lo[:m], up - q["du"]); hi[:m] = np.minimum(hi[:m], up + q["du"])
-        u, sw, rt, pd, adj, why = solve(H, f, c, lo, hi, q["U_guess"].T.reshape(-1), m, mode)
-        err = np.abs(u - q["U"].T.reshape(-1)).max()
-        worst = max(worst, err)
-        tot[why] = tot.get(why, 0) + 1
-        S += sw; R += rt; P += pd; A += adj
-    n = len(ap.CAPTURE)
-    print("%s solves %d %s sweeps/solve %.2f ratios %.2f pdas-its %.2f adjoint passes %.2f worst err %.1e" % (mode, n, tot, S / n, R / n, P / n, A / n, worst))
+if __name__ == "__main__":
+    cfg, order, members = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    ap.capture_loop(cfg, order, members)
+    for mode in ("grad", "nograd"):
+        tot = {}; S = R = P = A = 0; worst = 0
+        for q in ap.CAPTURE:
+            x_init, X_bm, U_bm, Q_ls, R_ls, A_ls, B_ls, D_ls = q["args"]
+            m, T = U_bm.shape
+            if "H" not in q:
+                q["H"], q["f"], q["c"] = ap.condense(x_init, np.asarray(X_bm, dtype=complex), np.asarray(U_bm, dtype=float), Q_ls, R_ls, A_ls, B_ls, D_ls)
+            H, f, c = q["H"], q["f"], q["c"]
+            lo = -q["sat"] * np.ones(T * m); hi = q["sat"] * np.ones(T * m)
+            if q["du"] is not None and q["u_prev"] is not None:
+                up = np.reshape(q["u_prev"], -1).real
+                lo[:m] = np.maximum(lo[:m], up - q["du"]); hi[:m] = np.minimum(hi[:m], up + q["du"])
+            u, sw, rt, pd, adj, why = solve(H, f, c, lo, hi, q["U_guess"].T.reshape(-1), m, mode)
+            err = np.abs(u - q["U"].T.reshape(-1)).max()
+            worst = max(worst, err)
+            tot[why] = tot.get(why, 0) + 1
+            S += sw; R += rt; P += pd; A += adj
+        n = len(ap.CAPTURE)
+        print("%s solves %d %s sweeps/solve %.2f ratios %.2f pdas-its %.2f adjoint passes %.2f worst err %.1e" % (mode, n, tot, S / n, R / n, P / n, A / n, worst))
