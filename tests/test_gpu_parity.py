@@ -509,6 +509,18 @@ def test_closed_loop_exact_qp_vs_oracle(cfg, order, batch, horizon, path):
     assert clip["qp_stats"] == (0, 0, 0, 0, 0, 0)
 
 
+def test_exact_qp_iteration_counts_config3():
+    """What the exact mode costs on BASELINE config 3 (T = 40, 20 steps): with the primal-dual phase for the hard solves (the first
+    warm steps) a solve takes 2.8 pinned sweeps on average and almost no ratio steps (round 2: 3.4 sweeps and 1.0 ratio step), and
+    every solve ends by the KKT test.  A guard: a change that silently sends solves back to the slow path shows up here."""
+    p = configs.build(3, batch=512)
+    res = _gpu_batch(p, np.arange(512), exact_qp=True)
+    n_solves, sweeps, ratio_steps, end_kkt, end_precision, end_cap = res["qp_stats"]
+    assert np.all(res["exit_codes"] == 0) and end_cap == 0 and end_kkt + end_precision == n_solves and end_precision <= 2
+    assert sweeps <= 3.1 * n_solves, (sweeps, n_solves)
+    assert ratio_steps <= 0.15 * n_solves, (ratio_steps, n_solves)
+
+
 def test_exact_qp_session_rejects_ref_lqr():
     p = configs.build(1, batch=1)
     with pytest.raises(_lib.M4qError):

@@ -19,10 +19,12 @@ ap.add_argument("--batch", type=int, default=16384)
 a = ap.parse_args()
 MODES = [("config3 real", 3, {}), ("config3 complex", 3, {"force_complex": True}), ("config3 exact real", 3, {"exact_qp": True}),
          ("config3 exact complex", 3, {"exact_qp": True, "force_complex": True}), ("config4 real", 4, {}),
-         ("config4 complex", 4, {"force_complex": True}), ("config2 real", 2, {}), ("config5 real (T=80)", 5, {})]
+         ("config4 complex", 4, {"force_complex": True}), ("config2 real", 2, {}), ("config5 real (T=80)", 5, {}),
+         ("config3 real, 9 coordinates", 3, {"traceless": False}), ("config3 tile sweeps", 3, {"tile": True}),
+         ("config4 exact real", 4, {"exact_qp": True}), ("config2 exact real", 2, {"exact_qp": True})]
 sessions = []
 for name, cfg, kw in MODES:
-    B = a.batch if "exact complex" not in name and "config4 complex" not in name else a.batch // 4
+    B = a.batch if "exact complex" not in name and "config4 complex" not in name and "config4 exact" not in name else a.batch // 4
     p = configs.build(cfg, batch=B, host_models=False)
     n, m, T, ns = p["dim_x"], p["dim_u"], p["horizon"], p["n_steps"]
     s = m4q.EnsembleSession(B, n, m, p["order"], T, ns, p["dt"], p["sat"], p["du"], model_per_instance=True, target_cols=ns + T + 1, **kw)
