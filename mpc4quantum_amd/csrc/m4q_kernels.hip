@@ -146,6 +146,12 @@ struct RowStash {
 // TL: the state lives in the NX - 1 traceless coordinates (S = double only; m4q_mpc.h).  NS = dimension of the recursion;
 // the I/O side (xs, the SQP-guess checkpoint, the plant) stays NX complex numbers per node.
 // TILE: the two sweeps of the clipped solve run on fp64 matrix-core tiles (m4q_tile.h) instead of DPP rows.
+// EXACT: further cuts of an instance's run after step 2 (strictly increasing, > 2; see the kernel)
+#ifndef M4Q_EXACT_CUTS
+#define M4Q_EXACT_CUTS 5
+#endif
+constexpr int XCUTS[] = {M4Q_EXACT_CUTS};
+constexpr int NXC = (int)(sizeof(XCUTS) / sizeof(int));
 #ifndef M4Q_WAVES_EXACT
 #define M4Q_WAVES_EXACT(S) WavesFor<S>::value
 #endif
@@ -193,6 +199,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
   volatile M4Q_LDS double* tgb = (volatile M4Q_LDS double*)(tiw + ROWS * TILE_IO_WORDS);
   int T0, flags;
   bool ls_diag, two_phase;
+  int n_pieces;                // work items per instance: head [step_begin, 2), then [2, XCUTS[0]), ... , [.., step_end)
+  auto piece_cut = [](int i) __attribute__((always_inline)) {       // where piece i (>= 1) begins
+    int v = 2;
+#pragma unroll
+    for (int k = 0; k < NXC; ++k)
+      if (i == k + 2) v = XCUTS[k];
+    return v;
+  };
+  auto piece_of = [&](int begin, int step_begin) __attribute__((always_inline)) {   // which piece begins there
+    int ph = begin == step_begin ? 0 : 1;
+#pragma unroll
+    for (int k = 0; k < NXC; ++k)
+      if (begin == XCUTS[k] && begin != step_begin) ph = k + 2;
+    return ph;
+  };
   {
     KArgs* a = kargs();
     T0 = a->T;
@@ -208,6 +229,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
     }
     // cut the run in two work items per instance when the launch covers both regimes
     two_phase = a->step_begin < 2 && a->step_end > 2;
+    // EXACT: a third piece.  The hard solves of the exact mode are the first warm steps (their shifted guess is poor: 30-130
+    // active-set iterations against 1-2), so a tail [2, step_end) is as uneven as a head; cut again (XCUTS) the launch drains on the
+    // late steps' uniform one-sweep solves instead (measured on config 3: no cut 255 ms, at 8 245-247, at 6 236-239, at 5 233, at 4 244).
+    n_pieces = two_phase ? 2 : 1;
+    if constexpr (EXACT) {
+#pragma unroll
+      for (int i = 0; i < NXC; ++i)
+        if (two_phase && a->step_end > XCUTS[i]) ++n_pieces;
+    }
     // Watchdog.  The loop below ends when the queue is empty and every row has finished, and a tail item waits for a flag another
     // workgroup sets: exits that depend on data.  A persistent kernel whose wavefronts never finish takes the GPU (and on this pool
     // the host's other GPUs) down with it, so every wavefront also leaves once the constant 100 MHz clock has advanced
@@ -283,7 +313,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
     // ---- rows without work draw the next item; tail items wait (without blocking) for their head ----
     if (__any(need_new || pending)) {
       KArgs* a = kargs();
-      const int B = a->B, n_items = two_phase ? 2 * B : B;
+      const int B = a->B, n_items = n_pieces * B;
       const int step_begin = a->step_begin, step_end = a->step_end, mf = a->measure_freq;
       const long sXs = (long)(a->n_steps + 1) * NX, sUs = (long)a->n_steps * NU;
       int nb = 0;
@@ -292,20 +322,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
       if (need_new) {
         need_new = false;
         if (nb < n_items) {
-          const bool tail = two_phase && nb >= B;
-          b = tail ? nb - B : nb;
-          row_begin = tail ? 2 : step_begin;
-          row_end = (two_phase && !tail) ? 2 : step_end;
+          const int ph = nb / B;                               // 0 head, then the later pieces in order
+          b = nb - ph * B;
+          row_begin = ph == 0 ? step_begin : piece_cut(ph);
+          row_end = ph == n_pieces - 1 ? step_end : piece_cut(ph + 1);
           pending = true;
         }
       }
       // a tail item starts once the head of its instance has been published
+      // (head_done[b] counts the pieces of the instance that have been published)
       int ready = 1;
-      if (pending && two_phase && row_begin == 2 && jj == 0)
-        ready = __hip_atomic_load(a->head_done + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool later = two_phase && row_begin != step_begin;
+      if (pending && later && jj == 0)
+        ready = __hip_atomic_load(a->head_done + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= piece_of(row_begin, step_begin) ? 1 : 0;
       ready = row_bcast_int(ready);
       const bool fresh = pending && ready != 0;
-      if (__any(fresh && two_phase && row_begin == 2)) {
+      if (__any(fresh && later)) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
@@ -819,15 +851,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
           gst(a->steps_done, b, done_steps);
         }
       }
-      if (two_phase && __any(finished && row_end == 2)) {
+      if (two_phase && __any(finished && row_end != kargs()->step_end)) {
         // head item: make the state visible to whichever workgroup draws the tail (G16: stores drained,
         // agent-scope release, drained again, then the flag)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (finished && row_end == 2 && jj == 0)
-          __hip_atomic_store(a->head_done + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (finished && row_end != a->step_end && jj == 0)
+          __hip_atomic_store(a->head_done + b, piece_of(row_begin, a->step_begin) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       if (finished) {
         active = false;
