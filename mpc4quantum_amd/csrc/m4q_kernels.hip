@@ -353,6 +353,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
         iter = 0;
         code = 0;
         done_steps = 0;
+        if (row_begin <= 1) {                                    // u_prev of steps 0 and 1: U_ref[:, 0] (mpc.py:185)
+          GView u0 = gview(a->u_targ, 0, 0);
+          u0.off = ut_off;
+#pragma unroll
+          for (int k = 0; k < NU; ++k) uprev[k] = u0.ld<double>(k);
+        }
       }
       if (__any(fresh && row_begin == 0)) {
         if (fresh && row_begin == 0) {
@@ -405,7 +411,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
           code = gld(a->codes, b);
           done_steps = gld(a->steps_done, b);
 #pragma unroll
-          for (int k = 0; k < NU; ++k) uprev[k] = gld(a->us, b * sUs + (long)(row_begin - 1) * NU + k);
+          for (int k = 0; k < NU; ++k) uprev[k] = row_begin > 1 ? gld(a->us, b * sUs + (long)(row_begin - 1) * NU + k) : uprev[k];
           if (code != 0) step = row_end;          // finished earlier (exit code set by the host or the device)
         }
       }
@@ -458,8 +464,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
       double lo0[NU], hi0[NU];
 #pragma unroll
       for (int k = 0; k < NU; ++k) {
-        // u_prev = us[step-1] if step > 1 else U_ref[:, 0] (mpc.py:185)
-        const double up = step > 1 ? uprev[k] : win.ubm.ld<double>(k);
+        // u_prev = us[step-1] if step > 1 else U_ref[:, 0] (mpc.py:185): `uprev` holds whichever applies (set when the row took its
+        // item and when a step ends) - read from the target array here it was a dependent global load in every pass of steps 0 and 1
+        const double up = uprev[k];
         lo0[k] = band ? up - du : -sat;
         hi0[k] = band ? up + du : sat;
       }
@@ -742,7 +749,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
       // apply U_opt[:, 0] (mpc.py:250), propagate the plant (mpc.py:256-260)
       if (ok) {
 #pragma unroll
-        for (int k = 0; k < NU; ++k) uprev[k] = uapp[k];
+        for (int k = 0; k < NU; ++k) uprev[k] = step >= 1 ? uapp[k] : uprev[k];     // (step 1 still takes U_ref[:, 0]: mpc.py:185)
         if (jj == 0) {
 #pragma unroll
           for (int k = 0; k < NU; ++k) gst(a->us, b * sUs + (long)step * NU + k, uapp[k]);
