@@ -38,12 +38,18 @@ def mac_per_hstep(n, m, P):
     return (2 * P + 2) * n * n + 2 * N ** 3 + 4 * m * N * N + n * n + n * m + m * N
 
 
-def executed_flop_per_hstep(n, m, P, path):
+def executed_flop_per_hstep(n, m, P, path, targ_const=False):
     """Arithmetic the selected path EXECUTES per horizon-step: complex recursion on n = d*d coordinates (8 flop per complex MAC),
-    the same recursion on real numbers in the Hermitian basis (2 flop per MAC), or on the n - 1 traceless coordinates."""
+    the same recursion on real numbers in the Hermitian basis (2 flop per MAC), or on the n - 1 traceless coordinates.
+    targ_const: the target is the same over the horizon window and the clipped real sweeps of a recursion of dimension >= 8 then
+    skip the row form of A_t and the product A_t xbar (csrc/m4q_kernels.hip: M4Q_TC_MIN_N): (P + 1) n^2 MACs fewer."""
     if path == "complex":
         return 8.0 * mac_per_hstep(n, m, P)
-    return 2.0 * mac_per_hstep(n - 1 if path.startswith("traceless") else n, m, P)
+    nr = n - 1 if path.startswith("traceless") else n
+    macs = mac_per_hstep(nr, m, P)
+    if targ_const and nr >= 8:
+        macs -= (P + 1) * nr * nr
+    return 2.0 * macs
 
 
 def compulsory_bytes(B, n, m, P, T, ns, path):
@@ -216,6 +222,8 @@ def main():
     else:
         models = p["models"] if p["models"] is not None else configs.build(args.config, batch=1)["models"]
     sess.load_problem(models, p["x0"], p["X_targ"], p["U_targ"], p["Q"], p["R"], p["Qf"], p["plant_op0"], p["plant_ops"])
+    # (a target that does not move over the run: the clipped sweeps take their constant-target form; not the exact mode's)
+    targ_const = (not args.exact_qp) and bool(np.all(p["X_targ"] == p["X_targ"][..., :1]))
     path = sess.path()                  # "real" / "complex": the dtype of the arithmetic
     detail = sess.path_detail()         # "complex" | "real" (d*d Hermitian coordinates) | "traceless" (d*d - 1) | "traceless-tile"
 
@@ -275,7 +283,7 @@ def main():
         # units of arithmetic per launch: horizon-steps; in the exact mode one pinned sweep + policy rollout over the horizon
         # is the arithmetic of one clipped solve
         hsteps = T * qp_stats[1] if qp_stats else units_per_step
-        flops_exec = executed_flop_per_hstep(n, m, P, detail) * hsteps
+        flops_exec = executed_flop_per_hstep(n, m, P, detail, targ_const) * hsteps
         flops_alg = ALG_FLOP[n] * hsteps
         cbytes = compulsory_bytes(B, n, m, P, T, ns, path)
         key = "config%d_B%d_%s_%s" % (args.config, B, path, "exact" if args.exact_qp else "clip")
@@ -320,7 +328,7 @@ def main():
                          "kernel": "mpc_kernel<%s, PLANT_HAMILTONIAN, %s>" % ("double" if path == "real" else "cplx",
                                                                               "true" if args.exact_qp else "false"),
                          "launches": launches, "avg_launch_ms": 1e3 * avg_launch_s,
-                         "flop_per_horizon_step": executed_flop_per_hstep(n, m, P, detail), "horizon_steps_per_launch": hsteps,
+                         "flop_per_horizon_step": executed_flop_per_hstep(n, m, P, detail, targ_const), "horizon_steps_per_launch": hsteps,
                          "note": "compute-bound kernel: intensity >> the fp64 machine balance, so the binding roof is fp64 FMA issue "
                                  "(v_fma_f64 with DPP row broadcasts; no MFMA instruction is executed - fp64 MFMA shares this pipe and "
                                  "peak).  achieved = flops of the arithmetic the selected path EXECUTES (real path: a quarter of SURVEY "

@@ -146,6 +146,11 @@ struct RowStash {
 // TL: the state lives in the NX - 1 traceless coordinates (S = double only; m4q_mpc.h).  NS = dimension of the recursion;
 // the I/O side (xs, the SQP-guess checkpoint, the plant) stays NX complex numbers per node.
 // TILE: the two sweeps of the clipped solve run on fp64 matrix-core tiles (m4q_tile.h) instead of DPP rows.
+#ifndef M4Q_TC_MIN_N
+#define M4Q_TC_MIN_N 8        // smallest recursion dimension that gets the constant-target instantiation of the sweep (round 2: 15 -
+                              // at d = 3 the second instantiation cost more in register allocation than it saved; with round 3's lower
+                              // pressure it pays: config 3 41.3 -> 40.3 ms, config 5's share 138.1 -> 134.7; d = 2 indifferent)
+#endif
 // EXACT: further cuts of an instance's run after step 2 (strictly increasing, > 2; see the kernel)
 #ifndef M4Q_EXACT_CUTS
 #define M4Q_EXACT_CUTS 5
@@ -542,9 +547,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
 #endif
       } else if constexpr (!EXACT) {
         // (xbar_t the same for every t: the sweep needs no row form of A_t - wave-uniform choice between two instantiations.
-        //  n = 16 real path only: config 4 85.5 -> 84.2 ms; at n = 9 the kernel with both instantiations is SLOWER, 50.65 -> 51.7 ms,
-        //  although it executes 27 vector instructions fewer per horizon index - profiles/r02_ab_experiments.txt)
-        constexpr bool HAS_TC = M4Q_TARG_CONST && NS >= 15 && sizeof(S) == sizeof(double);
+        //  Round 2: n = 16 only - config 4 85.5 -> 84.2 ms, while at n = 9 the kernel with both instantiations was SLOWER, 50.65 -> 51.7 ms,
+        //  although it executes 27 vector instructions fewer per horizon index (profiles/r02_ab_experiments.txt).  Round 3, with the
+        //  kernel off the register ceiling: n >= 8 - M4Q_TC_MIN_N above.)
+        constexpr bool HAS_TC = M4Q_TARG_CONST && NS >= M4Q_TC_MIN_N && sizeof(S) == sizeof(double);
         bool tc = false;
         if constexpr (HAS_TC) tc = (flags & QP_TARG_CONST) != 0;
         if constexpr (HAS_TC) {

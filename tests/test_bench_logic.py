@@ -22,6 +22,9 @@ def test_executed_flops_and_compulsory_bytes():
     assert b.executed_flop_per_hstep(9, 2, 2, "real") == b.executed_flop_per_hstep(9, 2, 2, "complex") / 4
     assert b.executed_flop_per_hstep(9, 2, 2, "traceless") == 2.0 * b.mac_per_hstep(8, 2, 2) == 5176.0
     assert b.executed_flop_per_hstep(9, 2, 2, "traceless-tile") == 5176.0
+    # constant target: the clipped real sweeps of a recursion of dimension >= 8 skip the row form of A_t and A_t xbar
+    assert b.executed_flop_per_hstep(9, 2, 2, "traceless", targ_const=True) == 5176.0 - 2 * 3 * 64
+    assert b.executed_flop_per_hstep(4, 1, 1, "traceless", targ_const=True) == b.executed_flop_per_hstep(4, 1, 1, "traceless")
     assert abs(b.executed_flop_per_hstep(16, 3, 3, "complex") - 126e3) < 2e3
     # config 3, real path: model 8*9*27, x0 (16+8)*9, xs 16*9*21, us 8*2*20, guess 16*9*41 + 8*2*40, codes and counts 8 + 80
     per = 8 * 9 * 27 + 24 * 9 + 16 * 9 * 21 + 8 * 2 * 20 + 16 * 9 * 41 + 8 * 2 * 40 + 8 + 80
