@@ -97,7 +97,14 @@ struct LaneGeo {
 constexpr int COST_ELEMS = 2 * NX * NX + NU * NU;         // Q, Qf, R staged in LDS once per workgroup
 constexpr int WLS_DOUBLES = 4 * NX + 2 * NU;               // diagonal line-search weights, staged after them
 constexpr int STASH_INTS = 12;                             // per-row words of RowStash
-constexpr int STASH_BYTES = 8 /* watchdog deadline */ + ROWS * STASH_INTS * 4 + 64 * 16 /* x_meas, one S per lane */;
+// The complex path parks x_meas in the plant / basis-change scratch (idle during a solve: 108 complex slots at d = 3, 64 needed)
+// instead of a block of its own: with one the kernel needed 21,480 B of LDS, a seventh of a CU's 160 KB was 1,000 B too small for an
+// eighth workgroup, and the launch ran on 1,792 wavefronts instead of 2,048 (round 3's +3.5 % on that path until this was seen in
+// SQ_WAVE_CYCLES / GRBM_GUI_ACTIVE: 54 against 63).
+template <class S> constexpr bool stash_x_in_scratch() { return sizeof(S) == sizeof(cplx) && ROWS * SCRATCH_ELEMS >= 64; }
+template <class S> constexpr int stash_bytes() {
+  return 8 /* watchdog deadline */ + ROWS * STASH_INTS * 4 + (stash_x_in_scratch<S>() ? 0 : 64 * 16) /* x_meas, one S per lane */;
+}
 
 // sizes of the staged model and costs for a recursion on N coordinates
 template <int N> constexpr int model_elems() { return (1 + NP) * N * ModelPitch<N>::value; }
@@ -107,7 +114,7 @@ template <class S, bool TL = false, bool TILE = false>
 constexpr size_t mpc_lds_layout_bytes() {
   constexpr int N = TL ? NX - 1 : NX;
   return sizeof(S) * (size_t)(ROWS * model_elems<N>() + cost_elems<N>()) + sizeof(cplx) * (size_t)(ROWS * SCRATCH_ELEMS) +
-         sizeof(double) * (size_t)WLS_DOUBLES + (size_t)STASH_BYTES + (TILE ? (size_t)TILE_LDS_BYTES : 0);
+         sizeof(double) * (size_t)WLS_DOUBLES + (size_t)stash_bytes<S>() + (TILE ? (size_t)TILE_LDS_BYTES : 0);
 }
 
 __device__ __forceinline__ int row_bcast_int(int v) { return __shfl(v, 0, 16); }
@@ -197,7 +204,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
   volatile M4Q_LDS unsigned long long* wd_slot = (volatile M4Q_LDS unsigned long long*)(ldsW + WLS_DOUBLES);
   RowStash<S> stash;
   stash.w = (volatile M4Q_LDS int*)(ldsW + WLS_DOUBLES + 1);
-  stash.xm = (volatile M4Q_LDS double*)(stash.w + ROWS * STASH_INTS);
+  stash.xm = stash_x_in_scratch<S>() ? (volatile M4Q_LDS double*)m4q_lds_raw : (volatile M4Q_LDS double*)(stash.w + ROWS * STASH_INTS);
   // TILE: hand-over block between the DPP-row state machine and the tile sweeps, and the G / h broadcast tiles
   volatile M4Q_LDS double* tio = stash.xm + 64 * 2;
   volatile M4Q_LDS int* tiw = (volatile M4Q_LDS int*)(tio + ROWS * TILE_IO_DOUBLES);
