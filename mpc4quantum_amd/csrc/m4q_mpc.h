@@ -16,6 +16,14 @@
 #define M4Q_HOIST_MODEL 1    // real path, n = 16: ROW form of the model in registers over a sweep (92.9 -> 85.8 ms; both forms: 87.5,
                              // 209 spills; a per-index batch as for n <= 9: 92.9)
 #endif
+#ifndef M4Q_BWD_HOIST_SMALL
+#define M4Q_BWD_HOIST_SMALL 1   // constant-target sweep, n <= 9: the N_p rows and column j of Q held in registers over the sweep, the column
+                                // form of the model read in one batch per index (round 3: 39.4 -> 38.6 -> 38.25 ms on config 3)
+#endif
+#ifndef M4Q_FWD_HOIST_SMALL
+#define M4Q_FWD_HOIST_SMALL 1   // rollout, n <= 9: the row form of the model held in registers over the rollout instead of one batch per index
+                                // (round 2, at the register ceiling: lost; round 3: 40.4 -> 39.4 ms on config 3.  The exact mode's rollouts: no gain.)
+#endif
 #ifndef M4Q_FWD_BATCH
 #define M4Q_FWD_BATCH 1      // rollout: the row form read in one batch (51.2 -> 50.85 ms)
 #endif
@@ -329,6 +337,25 @@ struct FusedProv {
       S a = mld(mdl, ModelPitch<NX>::at(0, i, j));
 #pragma unroll
       for (int p = 0; p < NP; ++p) cmac_r(a, mld(mdl, ModelPitch<NX>::at(1 + p, i, j)), po.pu[p]);
+      Ac[i] = a;
+    }
+  }
+  // col() with its (1 + NP) NX LDS reads issued as one batch
+  __device__ __forceinline__ void col_batch(const Lin& l, S (&Ac)[NX]) const {
+    Poly<NU, ORDER> po;
+    po.eval(l.u);
+    S col[1 + NP][NX];
+#pragma unroll
+    for (int p = 0; p <= NP; ++p) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) col[p][i] = mld(mdl, ModelPitch<NX>::at(p, i, j));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      S a = col[0][i];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) cmac_r(a, col[1 + p][i], po.pu[p]);
       Ac[i] = a;
     }
   }
@@ -686,8 +713,10 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
   // n = 16 real path: one wavefront per SIMD owns all 512 registers, and alone on its SIMD it cannot hide the LDS
   // read-to-use latency of the model at every horizon index: the ROW form of the model is read once per sweep and kept in
   // registers (measured A/B on config 4: 92.9 -> 85.8 ms; profiles/r02_ab_experiments.txt)
-  constexpr bool HOIST = M4Q_HOIST_MODEL && std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && sizeof(S) == sizeof(double) &&
-                         NX >= 15;
+  constexpr bool HOIST_SMALL = M4Q_BWD_HOIST_SMALL && TC && !PINNED && M4Q_HOIST_MODEL && sizeof(S) == sizeof(double) && NX < 15 &&
+                               std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && batch_fits<NX, NU, Prov::ORDER_>();
+  constexpr bool HOIST = (M4Q_HOIST_MODEL && std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && sizeof(S) == sizeof(double) &&
+                          NX >= 15) || HOIST_SMALL;
   ModelRegs<S, NX, NU, Prov::ORDER_> mregs;
   if constexpr (HOIST) mregs.load_rows(prov.mdl, j);
   // constant target: real fused path with batched (n <= 9) or hoisted (n = 16, mode 2) model reads
@@ -695,6 +724,14 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
                         ((M4Q_LDS_BATCH && batch_fits<NX, NU, Prov::ORDER_>()) || HOIST);
   S tterm[PowTab<NU, Prov::ORDER_>::NP + 1];
   if constexpr (TCON) prov.target_terms(xb_next, tterm);
+  // the same family: column j of Q (the closed loop's stage cost does not change along the horizon) read once per sweep
+  constexpr bool QHOIST = M4Q_BWD_HOIST_SMALL && HOIST_SMALL;
+  S Qcol[NX];
+  if constexpr (QHOIST) {
+    const S* Q0 = cost.q(0, T);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) Qcol[i] = Q0[i * NX + j];
+  }
   auto step = [&](int t, const Ops& cur, Ops& nxt, const S (&Pc)[NX], const S pv, S (&Pn)[NX], S& pv_out) __attribute__((always_inline)) {
     M4Q_NO_HOIST();
     nxt = load(t > 0 ? t - 1 : 0);
@@ -706,7 +743,10 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
     const S xb1 = xb_next;
     S ax, Brow[NU], dlt;
     // (measured, config 3 real path, A/B on one box: 51.98 -> 50.38 ms; n = 16 would need 256 registers for the batch)
-    if constexpr (TCON && HOIST) {
+    if constexpr (TCON && HOIST_SMALL) {
+      prov.col_batch(lin, Ac);
+      prov.rows_tc(mregs, lin, tterm, ax, Brow, dlt);
+    } else if constexpr (TCON && HOIST) {
       prov.col(lin, Ac);
       prov.rows_tc(mregs, lin, tterm, ax, Brow, dlt);
     } else if constexpr (TCON) {
@@ -868,7 +908,7 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
     }
     const S* Qt = cost.q(t, T);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) Pn[i] = Qt[i * NX + j];
+    for (int i = 0; i < NX; ++i) Pn[i] = QHOIST ? Qcol[i] : Qt[i * NX + j];
     matmul_cols_hn_acc<NX>(Pn, Ac, PSc);                       // + Sx^H P Sx
 #pragma unroll
     for (int k = 0; k < NU; ++k) mac_lane_index<true, false, NX>(Pn, Kx[k], RK[k]);   // + Kx^H R Kx
@@ -1045,7 +1085,7 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
     return o;
   };
   constexpr bool HOIST = M4Q_HOIST_MODEL && std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && sizeof(S) == sizeof(double) &&
-                         NX >= 15;
+                         (NX >= 15 || (M4Q_FWD_HOIST_SMALL && batch_fits<NX, NU, Prov::ORDER_>()));
   ModelRegs<S, NX, NU, Prov::ORDER_> mregs;
   if constexpr (HOIST) mregs.load_rows(prov.mdl, j);
   // one horizon index: `cur` holds its operands, those of the next index are fetched into `nxt` meanwhile.  The loop
