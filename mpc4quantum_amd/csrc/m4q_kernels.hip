@@ -33,12 +33,14 @@ constexpr int MODEL_ELEMS = (1 + NP) * NX * PITCH;        // per instance, eleme
 constexpr int SCRATCH_ELEMS = (SQUARE ? DD * DD : 0) + 2 * NX;   // plant / basis-change scratch per instance (complex)
 constexpr int ROWS = 4;                                    // instances per wavefront
 
-// register budget: waves per SIMD the kernels are compiled for (512 / budget VGPRs per lane)
+// register budget: waves per SIMD the kernels are compiled for (512 / budget VGPRs per lane).  d = 2 was compiled for four until the
+// end of round 3: at 128 registers every d = 2 closed-loop kernel spilled (59-372 VGPRs), and its launches are chains of
+// dependent passes that a third and fourth wavefront do not shorten: config 2 5.3 -> 4.2 ms at two (131,072 members: 23.6 -> 19.5 ms).
 #ifndef M4Q_WAVES
-#define M4Q_WAVES ((M4Q_NX <= 4) ? 4 : (M4Q_NX <= 9) ? 2 : 1)
+#define M4Q_WAVES ((M4Q_NX <= 9) ? 2 : 1)
 #endif
 #ifndef M4Q_WAVES_REAL
-#define M4Q_WAVES_REAL ((M4Q_NX <= 4) ? 4 : (M4Q_NX <= 9) ? 2 : 1)
+#define M4Q_WAVES_REAL ((M4Q_NX <= 9) ? 2 : 1)
 #endif
 #define M4Q_OCC __attribute__((amdgpu_waves_per_eu(M4Q_WAVES, 8)))
 template <class S> struct WavesFor { static constexpr int value = M4Q_WAVES; };
