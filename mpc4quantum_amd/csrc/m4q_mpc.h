@@ -16,6 +16,9 @@
 #define M4Q_HOIST_MODEL 1    // real path, n = 16: ROW form of the model in registers over a sweep (92.9 -> 85.8 ms; both forms: 87.5,
                              // 209 spills; a per-index batch as for n <= 9: 92.9)
 #endif
+#ifndef M4Q_BWD_QHOIST_LARGE
+#define M4Q_BWD_QHOIST_LARGE 1  // n = 16 (one wavefront per SIMD, 384 of 512 registers used): column j of Q held over the sweep, 72.2 -> 71.1 ms
+#endif
 #ifndef M4Q_BWD_HOIST_SMALL
 #define M4Q_BWD_HOIST_SMALL 1   // constant-target sweep, n <= 9: the N_p rows and column j of Q held in registers over the sweep, the column
                                 // form of the model read in one batch per index (round 3: 39.4 -> 38.6 -> 38.25 ms on config 3)
@@ -725,7 +728,7 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
   S tterm[PowTab<NU, Prov::ORDER_>::NP + 1];
   if constexpr (TCON) prov.target_terms(xb_next, tterm);
   // the same family: column j of Q (the closed loop's stage cost does not change along the horizon) read once per sweep
-  constexpr bool QHOIST = M4Q_BWD_HOIST_SMALL && HOIST_SMALL;
+  constexpr bool QHOIST = (M4Q_BWD_HOIST_SMALL && HOIST_SMALL) || (M4Q_BWD_QHOIST_LARGE && HOIST && !PINNED);
   S Qcol[NX];
   if constexpr (QHOIST) {
     const S* Q0 = cost.q(0, T);
@@ -747,7 +750,7 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
       prov.col_batch(lin, Ac);
       prov.rows_tc(mregs, lin, tterm, ax, Brow, dlt);
     } else if constexpr (TCON && HOIST) {
-      prov.col(lin, Ac);
+      prov.col(lin, Ac);                       // (its 60 LDS reads as one batch: no change, 71.3 ms either way)
       prov.rows_tc(mregs, lin, tterm, ax, Brow, dlt);
     } else if constexpr (TCON) {
       prov.col_rows_tc(lin, tterm, Ac, ax, Brow, dlt);
