@@ -16,6 +16,9 @@
 #define M4Q_HOIST_MODEL 1    // real path, n = 16: ROW form of the model in registers over a sweep (92.9 -> 85.8 ms; both forms: 87.5,
                              // 209 spills; a per-index batch as for n <= 9: 92.9)
 #endif
+#ifndef M4Q_EXACT_TC
+#define M4Q_EXACT_TC 1          // exact mode: the pinned sweep's constant-target form with the same hoisted reads (config 3 exact 234-237 -> 222-224 ms)
+#endif
 #ifndef M4Q_BWD_QHOIST_LARGE
 #define M4Q_BWD_QHOIST_LARGE 1  // n = 16 (one wavefront per SIMD, 384 of 512 registers used): column j of Q held over the sweep, 72.2 -> 71.1 ms
 #endif
@@ -716,7 +719,7 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
   // n = 16 real path: one wavefront per SIMD owns all 512 registers, and alone on its SIMD it cannot hide the LDS
   // read-to-use latency of the model at every horizon index: the ROW form of the model is read once per sweep and kept in
   // registers (measured A/B on config 4: 92.9 -> 85.8 ms; profiles/r02_ab_experiments.txt)
-  constexpr bool HOIST_SMALL = M4Q_BWD_HOIST_SMALL && TC && !PINNED && M4Q_HOIST_MODEL && sizeof(S) == sizeof(double) && NX < 15 &&
+  constexpr bool HOIST_SMALL = M4Q_BWD_HOIST_SMALL && TC && (!PINNED || M4Q_EXACT_TC) && M4Q_HOIST_MODEL && sizeof(S) == sizeof(double) && NX < 15 &&
                                std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && batch_fits<NX, NU, Prov::ORDER_>();
   constexpr bool HOIST = (M4Q_HOIST_MODEL && std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && sizeof(S) == sizeof(double) &&
                           NX >= 15) || HOIST_SMALL;
@@ -1486,7 +1489,17 @@ __device__ __forceinline__ bool box_qp_iterate(const Prov& prov, int T, S x0, co
     r.moved() = false;
     r.was_pdas() = r.pdas();
     if (r.going()) ++r.iters;
+#if M4Q_EXACT_TC
+    // (constant target: the sweep's constant-target form, as in the clipped mode - a wave-uniform choice between two instantiations)
+    if constexpr (sizeof(S) == sizeof(double) && NX >= 8) {
+      if ((flags & QP_TARG_CONST) != 0) riccati_backward<S, NX, NU, Prov, true, true>(prov, Tf(), win, cost, flags, gains, j, r.going() && ok(), &pin);
+      else riccati_backward<S, NX, NU, Prov, true>(prov, Tf(), win, cost, flags, gains, j, r.going() && ok(), &pin);
+    } else {
+      riccati_backward<S, NX, NU, Prov, true>(prov, Tf(), win, cost, flags, gains, j, r.going() && ok(), &pin);
+    }
+#else
     riccati_backward<S, NX, NU, Prov, true>(prov, Tf(), win, cost, flags, gains, j, r.going() && ok(), &pin);
+#endif
     wave_sync();
     settle();
     clk.mark(10);
