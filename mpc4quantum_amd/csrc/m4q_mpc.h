@@ -16,6 +16,9 @@
 #define M4Q_HOIST_MODEL 1    // real path, n = 16: ROW form of the model in registers over a sweep (92.9 -> 85.8 ms; both forms: 87.5,
                              // 209 spills; a per-index batch as for n <= 9: 92.9)
 #endif
+#ifndef M4Q_ADJ_HOIST_SMALL
+#define M4Q_ADJ_HOIST_SMALL 1   // exact mode's adjoint pass, n <= 9, order 1: N_p rows in registers, column form in one batch (226-229 -> 221-224 ms)
+#endif
 #ifndef M4Q_EXACT_TC
 #define M4Q_EXACT_TC 1          // exact mode: the pinned sweep's constant-target form with the same hoisted reads (config 3 exact 234-237 -> 222-224 ms)
 #endif
@@ -998,10 +1001,20 @@ __device__ __forceinline__ void adjoint_pass(const Prov& prov, int T, const Wind
   };
   pin.nchg = 0;
   S lam = qrow_times<NX>(cost.q(T, T), csub(pin.Xk.template ld<S>(T * NX + j), win.xbm.ld<S>(T * NX + j)), j);
+  constexpr bool AHOIST = M4Q_ADJ_HOIST_SMALL && M4Q_HOIST_MODEL && std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value &&
+                          sizeof(S) == sizeof(double) && batch_fits<NX, NU, Prov::ORDER_>() && Prov::ORDER_ == 1;
+  ModelRegs<S, NX, NU, Prov::ORDER_> mregs;
+  if constexpr (AHOIST) mregs.load_rows(prov.mdl, j);
   auto step = [&](int t, const Ops& cur) __attribute__((always_inline)) {
     S Ac[NX], Brow[NU];
-    prov.col(cur.lin, Ac);
-    prov.brows(cur.lin, Brow);
+    if constexpr (AHOIST) {
+      prov.col_batch(cur.lin, Ac);
+#pragma unroll
+      for (int k = 0; k < NU; ++k) Brow[k] = dot_lane_index<false, false, NX>(cur.lin.xg, mregs.row[1 + k]);   // (order 1: monomial p is u_p)
+    } else {
+      prov.col(cur.lin, Ac);
+      prov.brows(cur.lin, Brow);
+    }
     const S* Rt = cost.r(t);
 #pragma unroll
     for (int k = 0; k < NU; ++k) {
