@@ -3,8 +3,14 @@
 (3-level transmon, n=9, m=2, T=40, n_steps=20, 65,536-member model ensemble per GPU).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config 3] [--batch B]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-         bench.py --gpus N --steps K --warmup W
+
+ONE invocation for any N.  With --gpus N > 1 and no launcher in the environment (WORLD_SIZE unset) this process is only the
+launcher: it never touches the GPU, starts N child processes of this same script - one rank per GPU, RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_PORT (a free port) / M4Q_UID_FILE (where rank 0 publishes the RCCL unique id) set - relays rank 0's single
+JSON line, and fails (stopping the siblings) when any rank fails or the deadline passes.  Under an external launcher
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`:
+WORLD_SIZE set) the process is one of the ranks and --gpus must agree with WORLD_SIZE.  `n_gpus` in the line is the number of
+ranks the RCCL communicator actually joined (an all-reduce of 1), not the flag.
 
 One "step" = one complete receding-horizon run (all n_steps MPC steps, every SQP iteration, plant
 propagation) of the rank's whole ensemble, inputs resident in HBM.  Unit of work = one MPC
@@ -161,9 +167,74 @@ def cpu_baseline(config, p, cores, seconds_budget=20.0, members_per_core=64):
                                         p["horizon"])}
 
 
+def visible_devices():
+    """GPUs a rank of this job could open, counted in a CHILD process (m4q_device_count there): the launcher itself must never
+    initialise the GPU (a process that has, and then starts ranks, is what takes these hosts down)."""
+    import subprocess
+    try:
+        res = subprocess.run([sys.executable, os.path.abspath(__file__), "--device-count"], stdout=subprocess.PIPE, timeout=300,
+                             cwd=ROOT)
+        return int(res.stdout.decode().strip().splitlines()[-1])
+    except Exception:
+        return -1
+
+
+def launch(args):
+    """--gpus N > 1 without an external launcher: this process starts the N ranks and never touches the GPU itself."""
+    from mpc4quantum_amd.distributed import launch_local_ranks
+    if not args.launch_check:
+        have = visible_devices()
+        if have < args.gpus:
+            sys.stderr.write("bench.py: --gpus %d but this node shows %d usable GPU(s) (m4q_device_count in a child process "
+                             "returned %d): refusing to start ranks that would share or miss a device\n" % (args.gpus, max(have, 0), have))
+            return 2
+    child = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    return launch_local_ranks(child, args.gpus, timeout=args.launch_timeout)
+
+
+def launch_check(args, rank, world):
+    """What a rank does under --launch-check: no device, no library.  The unique-id file exchange is the product's own
+    (distributed.exchange_unique_id, with a random token in place of RCCL's id), then every rank leaves a
+    `<uid file>.joined.<rank>` note holding the token it read and rank 0 counts the notes that carry ITS token - the
+    file-system stand-in for the all-reduce of 1 that gives `n_gpus` in the real run."""
+    from mpc4quantum_amd.distributed import exchange_unique_id
+    if rank == args.fail_rank:
+        sys.exit(3)
+    token, path = exchange_unique_id(rank, world, timeout=60.0, make_id=lambda: os.urandom(128))
+    env = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "M4Q_UID_FILE")}
+    note = "%s.joined.%d" % (path, rank)
+    with open(note + ".tmp", "w") as f:
+        json.dump({"token": token.hex(), "env": env, "pid": os.getpid()}, f)
+    os.replace(note + ".tmp", note)
+    if rank != 0:
+        return 0
+    ranks, t0 = {}, time.time()
+    while len(ranks) < world and time.time() - t0 < args.launch_timeout:
+        for r in range(world):
+            if r not in ranks:
+                try:
+                    ranks[r] = json.load(open("%s.joined.%d" % (path, r)))
+                except (OSError, ValueError):
+                    pass
+        time.sleep(0.01)
+    joined = [r for r, v in sorted(ranks.items()) if v["token"] == token.hex()]
+    for r in range(world):
+        try:
+            os.unlink("%s.joined.%d" % (path, r))
+        except OSError:
+            pass
+    print(json.dumps({"launch_check": True, "n_gpus": len(joined), "ranks": [ranks[r]["env"] for r in joined],
+                      "pids": [ranks[r]["pid"] for r in joined], "uid_file": path}))
+    return 0 if len(joined) == world else 1
+
+
 def main():
     if len(sys.argv) == 6 and sys.argv[1] == "--cpu-worker":
         return _cpu_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5]))
+    if len(sys.argv) == 2 and sys.argv[1] == "--device-count":
+        from mpc4quantum_amd import _lib
+        print(_lib.device_count())
+        return 0
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -178,11 +249,25 @@ def main():
                                                             "(M4Q_QP_EXACT_BOX); roofline flops then count pinned sweeps")
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: take the N > 1 code path (RCCL communicator, gather "
                                                               "buffers bound to the session, one gather per run) even with one rank")
+    ap.add_argument("--launch-timeout", type=float, default=3000.0, help="deadline (s) of the N ranks started by --gpus N")
+    ap.add_argument("--launch-check", action="store_true", help="rehearsal of the launch without any device: every rank reports "
+                                                                "its environment, the unique-id file is exchanged, rank 0 counts "
+                                                                "the ranks that joined and prints the one JSON line")
+    ap.add_argument("--fail-rank", type=int, default=-1, help="(with --launch-check) this rank exits 3 before joining: a test "
+                                                              "that a dying rank fails the launch")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher set WORLD_SIZE=%d: one of the two is wrong" % (args.gpus, world))
+    if args.launch_check:
+        return launch_check(args, rank, world)
     multi = world > 1 or args.force_dist
     comm = None
     dev_index = -1
@@ -269,12 +354,14 @@ def main():
     info = sess.info()
     if multi:
         elapsed = float(comm.allreduce([elapsed], "max")[0])               # MAX over ranks of the timed region
-        tot = comm.allreduce([float(units_per_step), float(ok)], "sum")
+        tot = comm.allreduce([float(units_per_step), float(ok), 1.0], "sum")
         units_total = float(tot[0])
         ok_total = int(tot[1])
+        joined = int(round(tot[2]))                                        # ranks the communicator really has
     else:
         units_total = float(units_per_step)
         ok_total = ok
+        joined = 1
 
     if rank == 0:
         value = units_total * args.steps / elapsed
@@ -312,13 +399,13 @@ def main():
         out = {
             "metric": "MPC horizon-steps/sec across batch (3-level transmon, T=40)" if args.config == 3
                       else "MPC horizon-steps/sec across batch (config %d)" % args.config,
-            "value": value, "unit": "MPC horizon-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "MPC horizon-steps/s", "n_gpus": joined, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64" if path == "real" else "c128", "data": "synthetic",
             "config": {"workload": "BASELINE config %d: d=%d (n=%d, m=%d), order %d, T=%d, n_steps=%d, %d ensemble members per GPU, "
                                    "per-instance models, full closed loop per step; %s arithmetic path (%s)" % (args.config, p["d"], n, m, p["order"], T, ns, B, path, detail),
                        "batch_per_gpu": B, "horizon": T, "n_steps": ns, "qp_solves_per_step": units_per_step // T,
-                       "instances_ok": ok_total, "parallelism": "ensemble-sharded x%d, one gather" % world,
+                       "instances_ok": ok_total, "parallelism": "ensemble-sharded x%d, one gather" % joined,
                        "grid": info["grid"], "lds_bytes": info["lds_bytes"], "hbm_resident_bytes": info["hbm_bytes"],
                        **({"qp_mode": "exact box-constrained (active set on the Riccati factorisation)",
                            "exact_qp_stats": dict(zip(("qp_solves", "pinned_sweeps", "ratio_steps", "end_kkt", "end_precision",
@@ -356,4 +443,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

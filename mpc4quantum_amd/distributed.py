@@ -121,21 +121,27 @@ def _launch_key():
     return "%s_%d_%s" % (port, ppid, start)
 
 
-def exchange_unique_id(rank, world, path=None, timeout=300.0):
+def exchange_unique_id(rank, world, path=None, timeout=300.0, make_id=None):
     """Rank 0 creates the RCCL unique id (m4q_comm_unique_id) and publishes it in a file (written aside and renamed: readers
-    see all of it or nothing); the others wait for the file.  M4Q_UID_FILE overrides the path."""
-    L = _lib.lib()
+    see all of it or nothing); the others wait for the file.  M4Q_UID_FILE overrides the path.
+    make_id: a callable returning the UNIQUE_ID_BYTES to publish instead of RCCL's id (the device-free launch rehearsal,
+    `bench.py --launch-check`, runs this same file protocol with a random token)."""
     path = path or os.environ.get("M4Q_UID_FILE") or os.path.join(tempfile.gettempdir(), "m4q_uid_" + _launch_key())
     n = _lib.UNIQUE_ID_BYTES
     if rank == 0:
-        buf = (C.c_char * n)()
-        _lib.check(L.m4q_comm_unique_id(C.cast(buf, C.c_void_p)))
+        if make_id is None:
+            buf = (C.c_char * n)()
+            _lib.check(_lib.lib().m4q_comm_unique_id(C.cast(buf, C.c_void_p)))
+            uid = bytes(buf)
+        else:
+            uid = bytes(make_id())
+            assert len(uid) == n
         if world > 1:
             tmp = "%s.%d.tmp" % (path, os.getpid())
             with open(tmp, "wb") as f:
-                f.write(bytes(buf))
+                f.write(uid)
             os.replace(tmp, path)
-        return bytes(buf), path
+        return uid, path
     t0 = time.time()
     while True:
         try:
@@ -147,6 +153,89 @@ def exchange_unique_id(rank, world, path=None, timeout=300.0):
         if time.time() - t0 > timeout:
             raise TimeoutError("rank %d: no RCCL unique id at %s after %.0f s (did rank 0 start?)" % (rank, path, timeout))
         time.sleep(0.01)
+
+
+def free_port():
+    """A TCP port nobody listens on right now (names the launch: MASTER_PORT is part of the unique-id file's key)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_local_ranks(argv, world, timeout=3000.0, env=None, out=None, err=None):
+    """Start `world` child processes of `argv` on this node, one per GPU, and wait for them: the launcher `bench.py --gpus N` and
+    any script built on `mpc_batch_sharded` use when no external launcher (`torch.distributed.run`) has set WORLD_SIZE.
+    The caller must not have touched the GPU and this function does not: children are started with subprocess (never exec), each
+    with RANK = LOCAL_RANK = r, WORLD_SIZE, MASTER_ADDR = 127.0.0.1, a free MASTER_PORT and one shared M4Q_UID_FILE (the file
+    rank 0 publishes the RCCL unique id in).  Rank 0's stdout is relayed to `out` line by line as it comes, the other ranks'
+    stdout is dropped, every rank's stderr goes to `err` (default: inherited).  Returns 0 when every rank exits 0.  When a rank fails, or the deadline
+    passes, the others are terminated (then killed) and the return code is that rank's (124 for the deadline): no rank is left
+    waiting inside a collective for a sibling that is gone."""
+    import subprocess
+    import sys
+    import threading
+    out = out or sys.stdout
+    log = sys.stderr                        # the launcher's own messages; `err` (None: inherited) is the ranks' stderr
+    port = free_port()
+    uid = os.path.join(tempfile.gettempdir(), "m4q_uid_%d_%d_%d" % (port, os.getpid(), int(time.time() * 1e3)))
+    base = dict(os.environ if env is None else env)
+    base.update(WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), M4Q_UID_FILE=uid)
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs between processes on these hosts
+    procs = []
+    for r in range(world):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(list(argv), env=e, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=err,
+                                      start_new_session=True))
+
+    def relay(stream):
+        for line in iter(stream.readline, b""):
+            out.write(line.decode(errors="replace"))
+            out.flush()
+
+    th = threading.Thread(target=relay, args=(procs[0].stdout,), daemon=True)
+    th.start()
+    deadline = time.time() + timeout
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            rc = bad[0][1] if bad[0][1] > 0 else 128 - bad[0][1]
+            log.write("launch: rank %d exited with code %d; stopping the other ranks\n" % bad[0])
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() > deadline:
+            rc = 124
+            log.write("launch: ranks %s still running after %.0f s; stopping them\n" % ([r for r, c in enumerate(codes) if c is None], timeout))
+            break
+        time.sleep(0.05)
+    if rc:
+        import signal
+        for p in procs:                     # each child leads its own process group (its CPU-baseline workers go with it)
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGTERM)
+                except OSError:
+                    pass
+        t_end = time.time() + 10.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                p.wait()
+    th.join(timeout=5.0)
+    for path in (uid,):
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+    return rc
 
 
 class RcclComm:

@@ -62,3 +62,76 @@ def test_usable_cores_is_positive_and_bounded():
     b = _bench()
     n = b.usable_cores()
     assert 1 <= n <= len(os.sched_getaffinity(0))
+
+
+# ---- the launcher: `bench.py --gpus N` starts N ranks itself ---------------------------------------------
+def _run_bench(*argv, env=None, timeout=120):
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "M4Q_UID_FILE"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, env=e, timeout=timeout, cwd=ROOT)
+
+
+def test_gpus_flag_starts_that_many_ranks_and_prints_one_line():
+    """No device: every rank reports its environment, the unique-id file travels from rank 0 to the others, rank 0 counts the
+    ranks that joined.  One JSON line on stdout, n_gpus = ranks that joined."""
+    res = _run_bench("--gpus", "2", "--launch-check")
+    assert res.returncode == 0, res.stderr.decode()
+    lines = [ln for ln in res.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2
+    assert [r["RANK"] for r in out["ranks"]] == ["0", "1"] and [r["LOCAL_RANK"] for r in out["ranks"]] == ["0", "1"]
+    assert all(r["WORLD_SIZE"] == "2" and r["MASTER_ADDR"] == "127.0.0.1" for r in out["ranks"])
+    assert len({r["MASTER_PORT"] for r in out["ranks"]}) == 1 and len({r["M4Q_UID_FILE"] for r in out["ranks"]}) == 1
+    assert len(set(out["pids"])) == 2                      # two processes, neither of them the launcher
+    assert not os.path.exists(out["uid_file"])             # the launcher cleans up after the ranks
+    res = _run_bench("--gpus", "4", "--launch-check")
+    assert json.loads(res.stdout.decode().strip())["n_gpus"] == 4
+
+
+def test_a_rank_that_dies_fails_the_launch_and_stops_its_siblings():
+    import time
+    t0 = time.time()
+    res = _run_bench("--gpus", "3", "--launch-check", "--fail-rank", "1", "--launch-timeout", "60")
+    assert res.returncode == 3                             # the dead rank's code, not a hang until rank 0's own deadline
+    assert time.time() - t0 < 30
+    assert res.stdout.decode().strip() == ""               # no result line from a launch that lost a rank
+    assert "rank 1 exited with code 3" in res.stderr.decode()
+
+
+def test_launcher_deadline_stops_ranks_that_never_finish():
+    import io
+    import subprocess
+    import sys
+    from mpc4quantum_amd.distributed import launch_local_ranks
+    err = io.StringIO()
+    marker = "m4q_launch_deadline_probe_%d" % os.getpid()
+    rc = launch_local_ranks([sys.executable, "-c", "import time; time.sleep(120)  # " + marker], 2, timeout=1.0, out=io.StringIO(),
+                            err=subprocess.DEVNULL)
+    assert rc == 124
+    left = subprocess.run(["ps", "-eo", "args"], stdout=subprocess.PIPE).stdout.decode()
+    assert marker not in left
+
+
+def test_gpus_flag_is_refused_when_it_disagrees_with_the_node_or_the_launcher():
+    # more ranks than GPUs (this container has none): refused before any rank starts, by a count taken in a child process
+    res = _run_bench("--gpus", "2")
+    assert res.returncode == 2 and b"usable GPU" in res.stderr and res.stdout.strip() == b""
+    # under an external launcher the flag must agree with WORLD_SIZE
+    res = _run_bench("--gpus", "4", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert res.returncode != 0 and b"WORLD_SIZE=2" in res.stderr
+
+
+def test_launcher_never_loads_the_hip_library():
+    """The launcher process must not touch the GPU: it may not even load libm4q_hip.so (static initialisers of a HIP library run
+    at dlopen).  Checked on the module level: bench.launch() and distributed.launch_local_ranks reach no _lib.lib() call."""
+    import ast
+    src = open(os.path.join(ROOT, "mpc4quantum_amd", "distributed.py")).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "launch_local_ranks"][0]
+    names = {n.attr for n in ast.walk(fn) if isinstance(n, ast.Attribute)} | {n.id for n in ast.walk(fn) if isinstance(n, ast.Name)}
+    assert "_lib" not in names and "lib" not in names
