@@ -135,3 +135,22 @@ def test_launcher_never_loads_the_hip_library():
     fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "launch_local_ranks"][0]
     names = {n.attr for n in ast.walk(fn) if isinstance(n, ast.Attribute)} | {n.id for n in ast.walk(fn) if isinstance(n, ast.Name)}
     assert "_lib" not in names and "lib" not in names
+
+
+def test_committed_parity_admissions_never_cover_the_headline():
+    """profiles/r04_parity_admissions.json is what the GPU parity tests allow to pass on the oracle-sensitivity clause.  It must hold
+    no entry for config 3 order 1 (the headline), config 1 or config 2 on any arithmetic path, and none for an exact-mode case."""
+    import re
+    d = json.load(open(os.path.join(ROOT, "profiles", "r04_parity_admissions.json")))
+    for case, steps in d["allowed"].items():
+        m = re.match(r"stepwise\[cfg(\d)-o(\d)-B\d+-T(\d+)-(\w+)\]$", case)
+        assert m, case
+        cfg, order = int(m.group(1)), int(m.group(2))
+        assert (cfg, order) not in ((1, 1), (1, 2), (2, 1), (3, 1)), case
+        assert steps == sorted(set(steps)) and all(0 <= s < 20 for s in steps)
+    # every allowed step is backed by a measured record with its errors and the oracle's own sensitivity
+    seen = {(r["case"], r["step"]) for r in d["measured"]}
+    assert seen == {(c, s) for c, v in d["allowed"].items() for s in v}
+    for r in d["measured"]:
+        for e, s_k, tol in zip(r["errs"], r["oracle_sensitivity"], r["fixed_bounds"]):
+            assert e <= tol + 10 * s_k

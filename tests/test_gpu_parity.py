@@ -2,6 +2,7 @@
 (a) outputs of the reference's own files (tests/golden/*.npz) and (b) the CPU oracle on the same
 seeded inputs.  fp64 tolerances: 1e-10 relative for one QP solve / one MPC step,
 1e-8 after a 20-step closed loop."""
+import json
 import os
 
 import numpy as np
@@ -20,6 +21,49 @@ DIMS = {"qubit": (2, 1), "transmon": (3, 2), "coupled": (4, 3)}
 
 def rel(a, b):
     return np.abs(np.asarray(a) - np.asarray(b)).max() / max(1.0, np.abs(np.asarray(b)).max())
+
+
+# ---- the audit trail of the sensitivity clause ("make the parity claim auditable again") ------------------------------
+# A teacher-forced MPC step that misses the fixed bounds (1e-10 on us[k], xs[k+1]; 1e-7 on the guesses left behind) may pass only
+# against TEN TIMES what the oracle itself moves under a 1e-15 perturbation of the guess the step starts from - and every such
+# admission is (i) recorded with its errors and the measured sensitivity, (ii) checked against the committed list
+# profiles/r04_parity_admissions.json: a step that is not on that list FAILS the suite; configurations with no entry there admit
+# nothing (the headline - config 3, order 1, T = 40 - and configs 1 and 2 on every arithmetic path among them).  Everything a run
+# admitted is written to gpurun_out/parity_admissions_measured.json for comparison with the committed record.
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_ADMISSIONS_FILE = os.path.join(ROOT, "profiles", "r04_parity_admissions.json")
+_ADMISSIONS = []
+
+
+def _expected_admissions(key):
+    try:
+        with open(_ADMISSIONS_FILE) as f:
+            return set(json.load(f)["allowed"].get(key, []))
+    except OSError:
+        return set()
+
+
+def _admit(key, step, errs, sens, tols):
+    """Record one use of the sensitivity clause and check it against the committed list."""
+    _ADMISSIONS.append({"case": key, "step": int(step), "errs": [float(e) for e in errs], "oracle_sensitivity": [float(v) for v in sens],
+                        "fixed_bounds": list(tols)})
+    if os.environ.get("M4Q_RECORD_ADMISSIONS"):         # the run that (re)generates the committed record: tools/parity_admissions.py
+        return
+    allowed = _expected_admissions(key)
+    assert step in allowed, ("step %d of %s needs the sensitivity clause and is not on the committed list %s (errs %s, oracle "
+                             "sensitivity %s)" % (step, key, sorted(allowed), errs, list(sens)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _dump_admissions():
+    yield
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_admissions_measured.json"), "w") as f:
+            json.dump({"admissions": _ADMISSIONS}, f, indent=1)
+    except OSError:
+        pass
 
 
 def test_device_present():
@@ -345,6 +389,75 @@ def test_plant_generator_vs_expm_with_dissipation(d, m):
             assert rel(out[b], ref) <= 1e-11
 
 
+def _blackman_pulse(ts, t0, tf, dt):
+    """The reference's test pulse (tests/util_qubits.py:9-17): a Blackman window sampled at dt, linearly interpolated."""
+    M = int((tf - t0) / dt)
+    return np.interp(ts, np.linspace(t0, tf, M), np.blackman(M), left=0, right=0)
+
+
+@pytest.mark.parametrize("system", ["qubit", "transmon", "coupled"])
+def test_vectorized_model_rollout_tracks_the_device_plant(system):
+    """The reference's one model-vs-plant check (tests/test_mpc4quantum.py:215-274, test_vectorization) with the device on
+    both sides: the bilinear model (`vectorize_me` on the |i><j| basis -> `discretize_homogeneous` on the GPU, order 2; order 1 at d = 4) rolled
+    out under a Blackman pulse with `DMDc.predict` (mpc.py:267's call shape) against the plant kernel stepping the same held
+    controls (`m4q_plant_step_batch`: Pade matrix exponential; the reference has qutip.mesolve there).  The reference's
+    criterion: the plant state within 0.1 of the model's mid-step average on more than 90 % of the points - on its qubit
+    (tests/util_qubits.py:60-91, wQ = wD = wR, dt = 0.5, 25 steps, unit amplitude), and on the transmon and coupled-qubit
+    systems of configs 3 and 4 at their own dt.  Plus what the Taylor truncation promises: the one-step model error is
+    O((dt |H|)^(order + 1)) and falls by ~2^(order + 1) when dt is halved."""
+    from mpc4quantum_amd.configs import SX, SZ
+    n_train = 25
+    order = 1 if system == "coupled" else 2              # (the device builds the (16, 3) shape at order 1 only: m4q_shapes.inc)
+    if system == "qubit":
+        d, dt, amp = 2, 0.5, [1.0]
+        H = [0.5 * (np.pi - np.pi) * SZ, 0.5 * SX]
+    else:
+        p = configs.build(3 if system == "transmon" else 4, batch=1)
+        d, dt = p["d"], p["dt"]
+        H = [p["plant_op0"][0]] + list(p["plant_ops"][0])
+        amp = [0.8 * p["sat"], -0.5 * p["sat"], 0.3 * p["sat"]][:len(H) - 1]
+    n, m = d * d, len(H) - 1
+    basis = [np.outer(np.eye(d)[i], np.eye(d)[j]) for i in range(d) for j in range(d)]
+    A_cts = [m4q.vectorize_me(h, basis) for h in H]
+    assert all(np.abs(a - m4q.liouvillian(h)).max() <= 1e-14 for a, h in zip(A_cts, H))
+    ts = np.arange(n_train) * dt
+    us = np.stack([a * _blackman_pulse(ts, 0, n_train * dt, dt) for a in amp])             # (m, n_train)
+    rho0 = np.zeros((d, d), dtype=complex)
+    rho0[0, 0] = 1
+    x0 = rho0.reshape(-1)
+
+    def rollouts(dt_k, us_k):
+        A = m4q.discretize_homogeneous_batch(A_cts, dt_k, order)[0]                         # device (discretize_kernel)
+        assert rel(A, m4q.discretize_homogeneous(A_cts, dt_k, order)) <= 1e-13
+        model = m4q.DMDc(n, n, A.shape[1] - n, A)
+        lib = m4q.create_library(order, m)[1:]
+        xs_lin, xs_me, one_step = [x0], [x0], []
+        for i in range(us_k.shape[1]):
+            lift_u = np.array([f(us_k[:, i:i + 1]) for f in lib]).reshape(-1, 1)
+            xs_lin.append(model.predict(xs_lin[-1], m4q.krtimes(lift_u, xs_lin[-1].reshape(-1, 1))).reshape(-1))
+            nxt = m4q.plant_step_batch(xs_me[-1][None], us_k[:, i][None], H[0], np.stack(H[1:]), dt_k)[0]
+            one_step.append(np.abs(model.predict(xs_me[-1], m4q.krtimes(lift_u, xs_me[-1].reshape(-1, 1))).reshape(-1) - nxt).max())
+            xs_me.append(nxt)
+        return np.array(xs_lin).T, np.array(xs_me).T, max(one_step)
+
+    xs_lin, xs_me, err1 = rollouts(dt, us)
+    # like with like: model and plant at the same instants (the sample times of this plant are known)
+    assert (np.abs(xs_me - xs_lin) < 0.1).mean() > 0.9, np.abs(xs_me - xs_lin).max()
+    # the reference's own statement: the model's mid-step average against the plant's samples; it does not know which end of
+    # the step mesolve reports ("Not sure where mesolve reports the value", :268) - one of the two alignments must hold
+    mid = 0.5 * (xs_lin[:, 1:] + xs_lin[:, :-1])
+    frac = max((np.abs(xs_me[:, :-1] - mid) < 0.1).mean(), (np.abs(xs_me[:, 1:] - mid) < 0.1).mean())
+    assert frac > 0.9, frac
+    # the plant is trace preserving and unitary; the order-2 model only approximately
+    assert np.abs(np.trace(xs_me[:, -1].reshape(d, d)) - 1) <= 1e-12
+    assert abs(np.vdot(xs_me[:, -1], xs_me[:, -1]).real - 1) <= 1e-12
+    # truncation order: the same pulse on a grid twice as fine - the worst one-step error falls by about 2^(order + 1)
+    ts2 = np.arange(2 * n_train) * dt / 2
+    us2 = np.stack([a * _blackman_pulse(ts2, 0, n_train * dt, dt) for a in amp])
+    _, _, err2 = rollouts(dt / 2, us2)
+    assert err1 > 0 and 0.6 * 2 ** (order + 1) <= err1 / err2 <= 1.5 * 2 ** (order + 1), (err1, err2)
+
+
 def test_qexperiment_simulate_shape_and_values():
     p = configs.build(3, batch=1)
     exp = m4q.QExperiment(p["plant_op0"][0], list(p["plant_ops"][0]))
@@ -558,7 +671,8 @@ def test_closed_loop_stepwise_teacher_forced(cfg, order, batch, horizon, path):
     Paths: "real" = what a Liouvillian model gets by default (the d*d - 1 traceless Hermitian coordinates), "real9" = the d*d
     Hermitian coordinates (M4Q_OPT_NO_TRACELESS), "tile" = traceless with the sweeps on matrix-core tiles (M4Q_OPT_TILE),
     "complex" = the general path.  A step may exceed the fixed bounds only by ten times what the ORACLE itself moves when the
-    guess the step starts from is perturbed by 1e-15 - and only the odd step may need that (at T = 80: steps 4 and 7)."""
+    guess the step starts from is perturbed by 1e-15, and only if profiles/r04_parity_admissions.json lists that step for that
+    case (_admit); config 3 order 1 (the headline) and configs 1, 2 admit nothing on any path."""
     if path in ("real9", "tile") and (cfg, order, horizon) not in ((2, 1, None), (3, 1, None), (4, 1, 12)):
         pytest.skip("the alternative real paths are exercised on one configuration per dimension")
     p = configs.build(cfg, batch=max(batch, 4) if cfg == 3 else batch, order=order, horizon=horizon)
@@ -577,7 +691,7 @@ def test_closed_loop_stepwise_teacher_forced(cfg, order, batch, horizon, path):
                           p["plant_ops"])
         assert sess.path_detail() == {"real": "traceless", "real9": "real", "tile": "traceless-tile", "complex": "complex"}[path]
         xs_t, us_t = np.swapaxes(xs, 1, 2), np.swapaxes(us, 1, 2)          # time-major, as the C ABI holds them
-        worst = 0.0
+        key = "stepwise[cfg%d-o%d-B%d-T%d-%s]" % (cfg, order, batch, T, path)
         admitted = []
         for k in range(ns):
             if k > 0:
@@ -594,16 +708,17 @@ def test_closed_loop_stepwise_teacher_forced(cfg, order, batch, horizon, path):
             errs = [rel(got["us"][:, k], us_t[:, k]), rel(got["xs"][:, k + 1], xs_t[:, k + 1]),
                     rel(got["x_guess"], np.stack([trace[b][k + 1][0].T for b in range(batch)])),
                     rel(got["u_guess"], np.stack([trace[b][k + 1][1].T for b in range(batch)]))]
-            worst = max(worst, max(errs))
             if not (max(errs[:2]) <= 1e-10 and max(errs[2:]) <= 1e-7):
-                # beyond the fixed bounds: admissible only where the oracle itself is that sensitive to its last bits
-                # (seen at T = 80 only: config 5, steps 4 and 7 - DESIGN.md section 3)
+                # beyond the fixed bounds: admissible only where the oracle itself is that sensitive to its last bits, and only
+                # on the steps the committed record lists for this case (_admit)
                 sens = np.max([_oracle_step_sensitivity(p, models, b, k, xs, us, trace[b][k]) for b in range(batch)], axis=0)
                 for e, s_k, tol in zip(errs, sens, (1e-10, 1e-10, 1e-7, 1e-7)):
                     assert e <= tol + 10 * s_k, (k, errs, sens.tolist())
+                _admit(key, k, errs, sens, (1e-10, 1e-10, 1e-7, 1e-7))
                 admitted.append(k)
             assert np.all(got["steps_done"] == k + 1) and np.all(got["exit_codes"] == 0)
-        assert T >= 80 or len(admitted) <= max(2, ns // 5), admitted      # (T = 80 is beyond fp64 step after step: DESIGN.md 3)
+        if (cfg, order) in ((1, 1), (1, 2), (2, 1), (3, 1)):
+            assert admitted == [] or os.environ.get("M4Q_RECORD_ADMISSIONS"), (key, admitted)       # the headline configuration and configs 1, 2: fixed bounds, every step
     finally:
         sess.close()
 
@@ -667,6 +782,7 @@ def test_closed_loop_exact_stepwise_teacher_forced(cfg, order, batch, path):
             if not (eu <= 1e-9 and ex <= 1e-9):
                 sens = np.max([_oracle_exact_step_sensitivity(p, models, b, k, xs, us, trace[b][k]) for b in range(batch)], axis=0)
                 assert eu <= 1e-9 + 10 * sens[0] / p["sat"] and ex <= 1e-9 + 10 * sens[1], (k, eu, ex, sens.tolist())
+                _admit("exact_stepwise[cfg%d-o%d-B%d-T%d-%s]" % (cfg, order, batch, p["horizon"], path), k, (eu, ex), sens, (1e-9, 1e-9))
                 admitted.append(k)
         assert len(admitted) <= ns // 4, admitted          # the sensitivity clause is for the odd step, not the rule
     finally:
@@ -790,21 +906,30 @@ def test_mpc_streaming_refits_the_model_object():
     p = configs.build(1, batch=1)
     A0 = p["models"][0]
 
-    def run(mod, clock_cls, exp, model, **kw):
+    def run(mod, clock_cls, exp, model, x0=None, **kw):
         clock = clock_cls(p["dt"], p["horizon"], p["n_steps"])
-        return mod(p["x0"][0], 1, 1, p["X_targ"], p["U_targ"], clock, exp, model, p["Q"], p["R"], p["Qf"], sat=p["sat"],
-                   du=p["du"], streaming=True, **kw)
+        return mod(p["x0"][0] if x0 is None else x0, 1, 1, p["X_targ"], p["U_targ"], clock, exp, model, p["Q"], p["R"], p["Qf"],
+                   sat=p["sat"], du=p["du"], streaming=True, **kw)
     exp = m4q.QExperiment(p["plant_op0"][0], list(p["plant_ops"][0]))
     (xs, us), mdl, code = run(m4q.mpc, m4q.StepClock, exp, m4q.OnlineDMDc.from_bootstrap(4, 4, 4, A0.copy(), alpha=1e-2),
                               progress_bar=False)
     oexp = orc.OracleQExperiment(p["plant_op0"][0], list(p["plant_ops"][0]))
     (xo, uo), omdl, co = run(orc.mpc, orc.OracleClock, oexp, m4q.OnlineDMDc.from_bootstrap(4, 4, 4, A0.copy(), alpha=1e-2))
     assert code == co == 0 and mdl._iteration == omdl._iteration == p["n_steps"]
-    # (free running over 20 steps of config 1: rounding differences drift to 1e-7; steps 0 and 1 - every SQP iteration
-    #  of them - to 1e-10, per-step parity of the rest is the teacher-forced tests')
+    # steps 0 and 1 - every SQP iteration of them - to 1e-10; the free-running rest against the ORACLE's own measured envelope
+    # (how far its run moves when x0 changes in the last bits), as the free-running closed-loop tests do - not a constant
     assert rel(us[:, :2], uo[:, :2]) <= 1e-10 and rel(xs[:, :3], xo[:, :3]) <= 1e-10
-    assert rel(us, uo) <= 1e-6 and rel(xs, xo) <= 1e-6
-    assert rel(mdl.A, omdl.A) <= 1e-6 and np.abs(mdl.A - A0).max() > 1e-6          # refitted, identically
+    eu, ex, eA = np.zeros(us.shape[1]), np.zeros(xs.shape[1]), 0.0
+    for scale in (1 + 1e-14, 1 - 1e-14, 1 + 7e-14, 1 - 5e-14):
+        (xv, uv), vmdl, _ = run(orc.mpc, orc.OracleClock, oexp, m4q.OnlineDMDc.from_bootstrap(4, 4, 4, A0.copy(), alpha=1e-2),
+                                x0=p["x0"][0] * scale)
+        eu = np.maximum(eu, np.maximum.accumulate(np.abs(uv - uo).max(axis=0)))
+        ex = np.maximum(ex, np.maximum.accumulate(np.abs(xv - xo).max(axis=0)))
+        eA = max(eA, np.abs(vmdl.A - omdl.A).max())
+    assert np.all(np.abs(us - uo).max(axis=0) <= 1e-9 + 100 * eu), (np.abs(us - uo).max(axis=0), eu)
+    assert np.all(np.abs(xs - xo).max(axis=0) <= 1e-9 + 100 * ex), (np.abs(xs - xo).max(axis=0), ex)
+    assert rel(us, uo) <= 1e-6 and rel(xs, xo) <= 1e-6                               # (and never beyond the old constant)
+    assert np.abs(mdl.A - omdl.A).max() <= 1e-9 + 100 * eA and np.abs(mdl.A - A0).max() > 1e-6   # refitted, identically
     clock = m4q.StepClock(p["dt"], p["horizon"], p["n_steps"])
     (x2, u2), _, _ = m4q.mpc(p["x0"][0], 1, 1, p["X_targ"], p["U_targ"], clock, exp, m4q.DMDc(4, 4, 4, A0), p["Q"], p["R"], p["Qf"],
                              sat=p["sat"], du=p["du"], progress_bar=False)
@@ -990,13 +1115,16 @@ def test_measure_freq(cfg, mf, path):
                                           p["Qf"], p["sat"], p["du"], measure_freq=mf,
                                           qp_mode="exact" if path.endswith("exact") else "qp")
     assert np.array_equal(res["qp_solves"], solves)
-    k = 2 * mf
-    # free running over 2 mf steps: a rounding difference anywhere is amplified by the loop (the per-step bound is the teacher-forced
-    # tests' 1e-10); config 1's loop drifts by 1e-7 over 20 steps
-    tol = 1e-6 if (path.endswith("exact") or cfg == 1) else 1e-8
+    # steps 0 and 1 (every SQP iteration of them) to 1e-10; the free-running rest against the ORACLE's own measured envelope (what
+    # its run moves by under last-bit perturbations of x0 and of the model), not against a constant; per-step parity is the
+    # teacher-forced tests'
     assert rel(res["us"][:, :, :2], us[:, :, :2]) <= 1e-10 and rel(res["xs"][:, :, :3], xs[:, :, :3]) <= 1e-10
-    assert rel(res["us"][:, :, :k], us[:, :, :k]) <= tol and rel(res["xs"][:, :, :k + 1], xs[:, :, :k + 1]) <= tol
-    assert rel(res["us"], us) <= 1e-4 and rel(res["xs"], xs) <= 1e-4
+    eu, ex = _envelope(p, np.arange(3), xs, us, measure_freq=mf, qp_mode="exact" if path.endswith("exact") else "qp")
+    du_k = np.abs(res["us"] - us).max(axis=(0, 1))
+    dx_k = np.abs(res["xs"] - xs).max(axis=(0, 1))
+    assert np.all(du_k <= 1e-9 + 100 * eu), (du_k, eu)
+    assert np.all(dx_k[1:] <= 1e-9 + 100 * ex[1:]), (dx_k, ex)
+    assert rel(res["us"], us) <= 1e-4 and rel(res["xs"], xs) <= 1e-4             # (and never beyond the old constant)
 
 
 def test_mpc_dropin_measure_freq_host_plant_equals_fused():
@@ -1530,6 +1658,27 @@ def test_bench_line_schema():
     assert abs(d["value"] - d["config"]["qp_solves_per_step"] * d["config"]["horizon"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 2 and c["value"] > 0 and c["unit"] == d["unit"] and "sample" in c
+
+
+def test_bench_gpus_flag_on_a_one_gpu_box():
+    """`bench.py --gpus 2` on a box with one GPU: refused (exit 2) before any rank starts, by a device count taken in a child
+    process - the launcher never opens the device; and `--gpus 1 --force-dist` (the N > 1 code path with one rank: RCCL
+    communicator, bound gather buffers, one gather per run) reports the number of ranks RCCL joined."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    have = int(subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--device-count"], capture_output=True, text=True,
+                              timeout=300, cwd=root, env=env).stdout.strip())
+    assert have >= 1
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(have + 1), "--steps", "1", "--batch", "256"],
+                         capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert out.returncode == 2 and "usable GPU" in out.stderr and out.stdout.strip() == ""
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "2", "--warmup", "1",
+                          "--batch", "512", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 1 and "x1" in d["config"]["parallelism"] and d["config"]["instances_ok"] == 512
 
 
 def test_config5_whole_ensemble_on_one_gpu():
