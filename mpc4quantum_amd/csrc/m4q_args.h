@@ -90,7 +90,7 @@ struct PlantArgs {
 // one entry per compiled (dim_x, dim_u, order)
 struct ShapeOps {
   int nx, nu, order, np, d;
-  size_t (*mpc_lds_bytes)(int real_path);
+  size_t (*mpc_lds_bytes)(int real_path, int exact_qp);
   int (*launch_mpc)(const MpcArgs&, int plant_kind, int real_path, int grid, hipStream_t);
   int (*launch_linearize)(const LinArgs&, hipStream_t);
   int (*launch_qp)(const QpArgs&, hipStream_t);

@@ -112,11 +112,15 @@ template <class S> constexpr int stash_bytes() {
 template <int N> constexpr int model_elems() { return (1 + NP) * N * ModelPitch<N>::value; }
 template <int N> constexpr int cost_elems() { return 2 * N * N + NU * NU; }
 
-template <class S, bool TL = false, bool TILE = false>
+// Transposed copies of Q and Qf behind the costs (CostRef<S, TR>, m4q_mpc.h): the exact mode on a recursion whose rows are 64 bytes
+// long (n = 8 doubles), where the row reads of (Q e)_j conflict
+template <class S, int N, bool EXACT> constexpr bool cost_transposed() { return EXACT && sizeof(S) == sizeof(double) && N == 8; }
+template <class S, bool TL = false, bool TILE = false, bool EXACT = false>
 constexpr size_t mpc_lds_layout_bytes() {
   constexpr int N = TL ? NX - 1 : NX;
-  return sizeof(S) * (size_t)(ROWS * model_elems<N>() + cost_elems<N>()) + sizeof(cplx) * (size_t)(ROWS * SCRATCH_ELEMS) +
-         sizeof(double) * (size_t)WLS_DOUBLES + (size_t)stash_bytes<S>() + (TILE ? (size_t)TILE_LDS_BYTES : 0);
+  return sizeof(S) * (size_t)(ROWS * model_elems<N>() + cost_elems<N>() + (cost_transposed<S, N, EXACT>() ? 2 * N * N : 0)) +
+         sizeof(cplx) * (size_t)(ROWS * SCRATCH_ELEMS) + sizeof(double) * (size_t)WLS_DOUBLES + (size_t)stash_bytes<S>() +
+         (TILE ? (size_t)TILE_LDS_BYTES : 0);
 }
 
 __device__ __forceinline__ int row_bcast_int(int v) { return __shfl(v, 0, 16); }
@@ -198,7 +202,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
   const int jio = L.j;                           // ... and its slot of vec(rho) on the I/O side
   const bool lane_ok = jj < NS, lane_io = L.lane_ok;
   double tau = 0.0;                              // TL: the member's trace coordinate tr(rho)/sqrt(d) (row-uniform)
-  constexpr int MODEL_K = model_elems<NS>(), COST_K = cost_elems<NS>();
+  constexpr bool QTR = cost_transposed<S, NS, EXACT>();
+  constexpr int MODEL_K = model_elems<NS>(), COST_K = cost_elems<NS>() + (QTR ? 2 * NS * NS : 0);
   S* mdl = lds + g * MODEL_K;
   scratch += g * SCRATCH_ELEMS;
   S* ldsQ = lds + ROWS * MODEL_K;
@@ -237,6 +242,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
     const M4Q_GLOBAL S* gR = (const M4Q_GLOBAL S*)a->R;
     for (int e = threadIdx.x; e < 2 * NS * NS + NU * NU; e += 64)
       ldsQ[e] = e < NS * NS ? gld(gQ, e) : (e < 2 * NS * NS ? gld(gQf, e - NS * NS) : gld(gR, e - 2 * NS * NS));
+    if constexpr (QTR) {
+      for (int e = threadIdx.x; e < 2 * NS * NS; e += 64) {
+        const int blk = e / (NS * NS), r = (e / NS) % NS, c = e % NS;
+        ldsQ[cost_elems<NS>() + e] = gld(blk ? gQf : gQ, c * NS + r);
+      }
+    }
     ls_diag = a->Wls != nullptr;
     if (ls_diag) {
       for (int e = threadIdx.x; e < WLS_DOUBLES; e += 64) ldsW[e] = gld(a->Wls, e);
@@ -261,8 +272,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
     // horizon loops run T trips, the plant's squaring loop at most 60, the staging loops over fixed sizes.
     if (threadIdx.x == 0) *wd_slot = __builtin_amdgcn_s_memrealtime() + a->deadline_ticks;
   }
-  CostRef<S> cost;
+  CostRef<S, QTR> cost;
   cost.Q = ldsQ; cost.Qf = ldsQ + NS * NS; cost.q_stride = 0; cost.R = ldsQ + 2 * NS * NS; cost.r_stride = 0;
+  if constexpr (QTR) { cost.QT = ldsQ + cost_elems<NS>(); cost.QfT = cost.QT + NS * NS; }
   // workspace of this resident row: wave-uniform base per workgroup, lane part = row within the wave
   const unsigned sX = (unsigned)(T0 + 1) * NS, sU = (unsigned)T0 * NU, sG = (unsigned)T0 * (NS + 1) * NU;
   const unsigned sXc = (unsigned)(T0 + 1) * NX;            // the SQP-guess checkpoint field: complex, NX per node
@@ -552,7 +564,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
 #else
         // the rollout on DPP rows: one short dependent chain per index, where the tile form waits on every operand
         // (profiles/r03_phase_clock.txt: 3,060 cycles per index against 1,320)
-        chk = rollout_forward<S, NS, NU, false>(prov, T, x_cur, win, cost, flags, gains, sat, lo0, hi0, Xo, Uo, j, st, uapp, !use_ls, &Xg, &Ug);
+        // (idle lanes sit it out as in the DPP kernels: MASK_IDLE itself is off for TILE because the tile sweep needs all 64 lanes)
+        constexpr bool MASK_FWD = M4Q_MASK_IDLE && NS < 16;
+        if (!MASK_FWD || lane_ok)
+          chk = rollout_forward<S, NS, NU, false>(prov, T, x_cur, win, cost, flags, gains, sat, lo0, hi0, Xo, Uo, j, st, uapp, !use_ls, &Xg, &Ug);
+        if constexpr (MASK_FWD) {
+          chk = bcast<0>(chk);
+#pragma unroll
+          for (int k = 0; k < NU; ++k) uapp[k] = bcast<0>(uapp[k]);
+        }
 #endif
       } else if constexpr (!EXACT) {
         // (xbar_t the same for every t: the sweep needs no row form of A_t - wave-uniform choice between two instantiations.
@@ -1136,12 +1156,13 @@ __global__ __launch_bounds__(64) void discretize_kernel(DiscArgs a) {
 // ---------------------------------------------------------------------------------------------
 // host-side launchers for this shape
 // ---------------------------------------------------------------------------------------------
-static size_t mpc_lds_bytes(int path) {
+static size_t mpc_lds_bytes(int path, int exact) {
   if constexpr (SQUARE) {
     if (path == 3) return mpc_lds_layout_bytes<double, true, true>();
-    if (path == 2) return mpc_lds_layout_bytes<double, true, false>();
+    if (path == 2) return exact ? mpc_lds_layout_bytes<double, true, false, true>() : mpc_lds_layout_bytes<double, true, false>();
   }
-  return path ? mpc_lds_layout_bytes<double>() : mpc_lds_layout_bytes<cplx>();
+  if (path) return exact ? mpc_lds_layout_bytes<double, false, false, true>() : mpc_lds_layout_bytes<double>();
+  return mpc_lds_layout_bytes<cplx>();
 }
 
 template <class K>
@@ -1160,7 +1181,7 @@ struct LaunchOp {
   hipStream_t s;
   template <class S, int PLANT, bool EXACT, bool TL, bool TILE>
   int run() const {
-    const size_t lds = mpc_lds_layout_bytes<S, TL, TILE>();
+    const size_t lds = mpc_lds_layout_bytes<S, TL, TILE, EXACT>();
     int rc = prep_lds(mpc_kernel<S, PLANT, EXACT, TL, TILE>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL((mpc_kernel<S, PLANT, EXACT, TL, TILE>), dim3(grid), dim3(64), lds, s, a);
@@ -1172,7 +1193,7 @@ struct OccupancyOp {
   int run() const {
     int nb = 0;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mpc_kernel<S, PLANT, EXACT, TL, TILE>, 64,
-                                                                 mpc_lds_layout_bytes<S, TL, TILE>());
+                                                                 mpc_lds_layout_bytes<S, TL, TILE, EXACT>());
     return e != hipSuccess ? -(int)e : nb;
   }
 };

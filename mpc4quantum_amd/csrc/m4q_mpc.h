@@ -51,6 +51,7 @@ enum : int {
   QP_DU_BAND = 2,   // clip the first control to u_prev +- du as well (optimize.py:29-30)
   QP_EXACT_BOX = 4, // solve the box-constrained QP to optimality (projected Newton) instead of clipping the Riccati rollout
   QP_TARG_CONST = 256,   // internal (set by the host when every column of X_targ is the same): xbar_t does not depend on t
+  QP_UTARG_CONST = 512,  // internal (every column of U_targ the same): ubar_t does not depend on t - one load per sweep instead of one per index
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -332,8 +333,7 @@ struct FusedProv {
   };
   __device__ __forceinline__ Lin fetch(int t) const {
     Lin l;
-#pragma unroll
-    for (int k = 0; k < NU; ++k) l.u[k] = Ug.ld<double>(t * NU + k);
+    ldn<NU>(Ug, t * NU, l.u);
     l.xg = Xg.ld<S>(t * NX + j);
     return l;
   }
@@ -606,14 +606,22 @@ struct ExplicitProv {
 
 // Stage costs (shared by the ensemble, wave-uniform pointers; LDS in the fused kernel).
 // Q(t) for t < T, Qf at t == T; R(t).
-template <class S>
+// TR: transposed copies of Q and Qf are staged as well (QT, QfT).  (Q v)_j needs ROW j of Q in lane j; at a row pitch of 64 bytes
+// (n = 8 doubles, the traceless coordinates of d = 3) row owners j and j + 4 read the same LDS banks - the exact mode's rollouts
+// and adjoint pass form Q e at every horizon index and spent 9.2 % of their LDS-active cycles in bank conflicts
+// (profiles/r03_pmc_config3_B65536_real_exact.txt; the clipped kernels read columns only: 0.4 %).  Column j of Q^T is the same
+// numbers at consecutive addresses, whatever Q is (no symmetry assumed).
+template <class S, bool TR = false>
 struct CostRef {
   const S* Q;
   const S* Qf;
   long q_stride;   // elements between Q(t) and Q(t+1); 0 = constant
   const S* R;
   long r_stride;
+  const S* QT = nullptr;    // TR only (constant Q: q_stride == 0)
+  const S* QfT = nullptr;
   __device__ __forceinline__ const S* q(int t, int T) const { return t == T ? Qf : Q + (long)t * q_stride; }
+  __device__ __forceinline__ const S* qT(int t, int T) const { return t == T ? QfT : QT; }
   __device__ __forceinline__ const S* r(int t) const { return R + (long)t * r_stride; }
 };
 
@@ -630,6 +638,19 @@ __device__ __forceinline__ S qrow_times(const S* Qt, S v, int j) {
 #pragma unroll
   for (int i = 0; i < NX; ++i) qr[i] = Qt[j * NX + i];
   return dot_lane_index<false, false, NX>(v, qr);
+}
+// the same with the stage cost of horizon index t taken from `cost` (its transposed copy when there is one)
+template <int NX, class S, bool TR>
+__device__ __forceinline__ S qrow_times(const CostRef<S, TR>& cost, int t, int T, S v, int j) {
+  if constexpr (TR) {
+    const S* Qt = cost.qT(t, T);
+    S qr[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) qr[i] = Qt[i * NX + j];
+    return dot_lane_index<false, false, NX>(v, qr);
+  } else {
+    return qrow_times<NX>(cost.q(t, T), v, j);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -686,13 +707,16 @@ struct PinCtx {
   }
 };
 
-template <class S, int NX, int NU, class Prov, bool PINNED = false, bool TC = false>
-__device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const Window& win, const CostRef<S>& cost, int flags,
+template <class S, int NX, int NU, class Prov, bool PINNED = false, bool TC = false, bool TR = false>
+__device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const Window& win, const CostRef<S, TR>& cost, int flags,
                                                   const GView& gains, int j, bool store_ok, PinCtx<NU>* pin = nullptr) {
   const bool ref = (flags & QP_REF_LQR) != 0;
   S Pc[NX];
   S pv = zero_of<S>();
   S xb_next = win.xbm.ld<S>(T * NX + j);        // xbar_{t+1} of the first iteration
+  const bool uconst = (flags & QP_UTARG_CONST) != 0;
+  double ub0[NU];
+  ldn<NU>(win.ubm, 0, ub0);
   {
     const S* Qt = cost.q(T, T);
 #pragma unroll
@@ -710,13 +734,12 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
   auto load = [&](int t) __attribute__((always_inline)) {
     Ops o;
     o.lin = prov.fetch(t);
-    o.xb = win.xbm.ld<S>(t * NX + j);
+    if constexpr (TC) o.xb = xb_next;            // (constant target: the column loaded above serves every index)
+    else o.xb = win.xbm.ld<S>(t * NX + j);
 #pragma unroll
-    for (int k = 0; k < NU; ++k) o.ub[k] = win.ubm.ld<double>(t * NU + k);
-    if constexpr (PINNED) {
-#pragma unroll
-      for (int k = 0; k < NU; ++k) o.stv[k] = pin->stat.template ld<double>(t * NU + k);
-    }
+    for (int k = 0; k < NU; ++k) o.ub[k] = ub0[k];
+    if (!uconst) ldn<NU>(win.ubm, t * NU, o.ub);
+    if constexpr (PINNED) ldn<NU>(pin->stat, t * NU, o.stv);
     return o;
   };
   // n = 16 real path: one wavefront per SIMD owns all 512 registers, and alone on its SIMD it cannot hide the LDS
@@ -882,12 +905,8 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
     }
     if (store_ok) {
       const unsigned gt = (unsigned)t * (NX + 1) * NU;
-#pragma unroll
-      for (int k = 0; k < NU; ++k) gains.st<S>(gt + j * NU + k, Kst[k]);
-      if (j == 0) {
-#pragma unroll
-        for (int k = 0; k < NU; ++k) gains.st<S>(gt + NX * NU + k, kst[k]);
-      }
+      stn<NU>(gains, gt + j * NU, Kst);
+      stn<NU>(gains, gt + NX * NU, kst);           // (replicated over the row: every lane writes the same bytes - no exec mask to set up)
     }
 
     // closed loop: Sx = A_t + B Kx (column j, in place): Ac[i] += lane_i(B[i][k]) Kx[k];  s = c + B k
@@ -977,8 +996,8 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
 // Operands are fetched PF indices ahead (an index is too short to hide the workspace's latency behind the previous one; four
 // ahead spilled inside the loop).
 // ---------------------------------------------------------------------------------------------
-template <class S, int NX, int NU, class Prov>
-__device__ __forceinline__ void adjoint_pass(const Prov& prov, int T, const Window& win, const CostRef<S>& cost, PinCtx<NU>& pin, int j,
+template <class S, int NX, int NU, class Prov, bool TR = false>
+__device__ __forceinline__ void adjoint_pass(const Prov& prov, int T, const Window& win, const CostRef<S, TR>& cost, PinCtx<NU>& pin, int j,
                                              bool store_ok) {
   constexpr int PF = 2;
   struct Ops {
@@ -991,16 +1010,13 @@ __device__ __forceinline__ void adjoint_pass(const Prov& prov, int T, const Wind
     o.lin = prov.fetch(t);
     o.xb = win.xbm.ld<S>(t * NX + j);
     o.xk = pin.Xk.template ld<S>(t * NX + j);
-#pragma unroll
-    for (int k = 0; k < NU; ++k) {
-      o.ub[k] = win.ubm.ld<double>(t * NU + k);
-      o.stv[k] = pin.stat.template ld<double>(t * NU + k);
-      o.uk[k] = pin.Uk.template ld<double>(t * NU + k);
-    }
+    ldn<NU>(win.ubm, t * NU, o.ub);
+    ldn<NU>(pin.stat, t * NU, o.stv);
+    ldn<NU>(pin.Uk, t * NU, o.uk);
     return o;
   };
   pin.nchg = 0;
-  S lam = qrow_times<NX>(cost.q(T, T), csub(pin.Xk.template ld<S>(T * NX + j), win.xbm.ld<S>(T * NX + j)), j);
+  S lam = qrow_times<NX>(cost, T, T, csub(pin.Xk.template ld<S>(T * NX + j), win.xbm.ld<S>(T * NX + j)), j);
   constexpr bool AHOIST = M4Q_ADJ_HOIST_SMALL && M4Q_HOIST_MODEL && std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value &&
                           sizeof(S) == sizeof(double) && batch_fits<NX, NU, Prov::ORDER_>() && Prov::ORDER_ == 1;
   ModelRegs<S, NX, NU, Prov::ORDER_> mregs;
@@ -1034,7 +1050,7 @@ __device__ __forceinline__ void adjoint_pass(const Prov& prov, int T, const Wind
       }
     }
     const S e = csub(cur.xk, cur.xb);
-    lam = dot_lane_index<false, true, NX>(lam, Ac, qrow_times<NX>(cost.q(t, T), e, j));   // Q_t e_t + A_t^H lam
+    lam = dot_lane_index<false, true, NX>(lam, Ac, qrow_times<NX>(cost, t, T, e, j));   // Q_t e_t + A_t^H lam
   };
   Ops ring[PF];
 #pragma unroll
@@ -1063,13 +1079,18 @@ __device__ __forceinline__ void adjoint_pass(const Prov& prov, int T, const Wind
 // step (alpha = 1, mpc.py:208-212) ends up with after its update and shift passes.  Safe in place: index
 // t of the guess has been read (one iteration ahead) before it is overwritten.
 // ---------------------------------------------------------------------------------------------
-template <class S, int NX, int NU, bool WANT_COST, class Prov>
-__device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0, const Window& win, const CostRef<S>& cost,
+template <class S, int NX, int NU, bool WANT_COST, class Prov, bool TR = false>
+__device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0, const Window& win, const CostRef<S, TR>& cost,
                                                    int flags, const GView& gains, double sat, const double (&lo0)[NU],
                                                    const double (&hi0)[NU], const GView& Xo, const GView& Uo, int j,
                                                    bool store_ok, double (&u_first)[NU], bool shift_out = false,
                                                    const GView* Xg = nullptr, const GView* Ug = nullptr) {
   const bool ref = (flags & QP_REF_LQR) != 0;
+  const bool tconst = (flags & QP_TARG_CONST) != 0;          // xbar_t the same for every t: loaded once
+  const S xb0 = win.xbm.ld<S>(j);
+  const bool uconst = (flags & QP_UTARG_CONST) != 0;
+  double ub0[NU];
+  ldn<NU>(win.ubm, 0, ub0);
   S x = x0;
   // destination views: lane offsets select between (Xo, Uo) and the shifted guess
   GView Xd = Xo, Ud = Uo;
@@ -1093,14 +1114,17 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
   auto load = [&](int t) __attribute__((always_inline)) {
     Ops o;
     o.lin = prov.fetch(t);
-    o.xb = win.xbm.ld<S>(t * NX + j);
+    o.xb = xb0;
+    if (!tconst) o.xb = win.xbm.ld<S>(t * NX + j);
     const unsigned gt = (unsigned)t * (NX + 1) * NU;
 #pragma unroll
-    for (int k = 0; k < NU; ++k) {
-      o.ub[k] = win.ubm.ld<double>(t * NU + k);
-      o.Kx[k] = gains.ld<S>(gt + j * NU + k);
-      o.kre[k] = real_of(gains.ld<S>(gt + NX * NU + k));
-    }
+    for (int k = 0; k < NU; ++k) o.ub[k] = ub0[k];
+    if (!uconst) ldn<NU>(win.ubm, t * NU, o.ub);
+    ldn<NU>(gains, gt + j * NU, o.Kx);
+    S kk[NU];
+    ldn<NU>(gains, gt + NX * NU, kk);
+#pragma unroll
+    for (int k = 0; k < NU; ++k) o.kre[k] = real_of(kk[k]);
     return o;
   };
   constexpr bool HOIST = M4Q_HOIST_MODEL && std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && sizeof(S) == sizeof(double) &&
@@ -1138,7 +1162,7 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
     if constexpr (WANT_COST) {
       const S* Rt = cost.r(t);
       const S e = ref ? xn : dx;
-      const S qe = qrow_times<NX>(cost.q(ref ? t + 1 : t, T), e, j);
+      const S qe = qrow_times<NX>(cost, ref ? t + 1 : t, T, e, j);
       cx += dot_re(e, qe);
 #pragma unroll
       for (int k = 0; k < NU; ++k) {
@@ -1157,16 +1181,12 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
     x = xn;
     if (store_ok) {
       Xd.st<S>((t + xs_shift) * NX + j, x);
-      if (j == 0 && t + us_shift >= 0) {
-#pragma unroll
-        for (int k = 0; k < NU; ++k) Ud.st<double>((t + us_shift) * NU + k, u[k]);
-      }
+      // (u is replicated over the row: every lane writes the same bytes.  A shifting row's u_0 has no slot: it goes to slot 0,
+      //  which the same lane's store of u_1 overwrites - no exec mask to set up)
+      stn<NU>(Ud, (unsigned)(t + us_shift > 0 ? t + us_shift : 0) * NU, u);
       if (shift_out && t == T - 1) {
         Xd.st<S>(T * NX + j, x);                       // repeat the last column
-        if (j == 0) {
-#pragma unroll
-          for (int k = 0; k < NU; ++k) Ud.st<double>((T - 1) * NU + k, u[k]);
-        }
+        stn<NU>(Ud, (T - 1) * NU, u);
       }
     }
     M4Q_PHASE();
@@ -1182,7 +1202,7 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
   if constexpr (WANT_COST) {
     if (!ref) {
       const S e = csub(x, win.xbm.ld<S>(T * NX + j));
-      const S qe = qrow_times<NX>(cost.q(T, T), e, j);
+      const S qe = qrow_times<NX>(cost, T, T, e, j);
       cx += dot_re(e, qe);
     }
   }
@@ -1228,8 +1248,8 @@ struct RolloutInfo {
 
 // closed-loop rollout of the policy in `gains` (pinned controls sit on their bound), with (clip) or without clipping
 // of the free controls.  Writes the trial point (Xc, Uc); returns the objective.
-template <class S, int NX, int NU, class Prov>
-__device__ __forceinline__ double rollout_policy(const Prov& prov, int T, S x0, const Window& win, const CostRef<S>& cost,
+template <class S, int NX, int NU, class Prov, bool TR = false>
+__device__ __forceinline__ double rollout_policy(const Prov& prov, int T, S x0, const Window& win, const CostRef<S, TR>& cost,
                                                  const GView& gains, const PinCtx<NU>& pin, const GView& Uk, bool clip,
                                                  const GView& Xc, const GView& Uc, int j, bool store_ok, RolloutInfo& info) {
   S x = x0;
@@ -1254,14 +1274,14 @@ __device__ __forceinline__ double rollout_policy(const Prov& prov, int T, S x0, 
     o.lin = prov.fetch(t);
     o.xb = win.xbm.ld<S>(t * NX + j);
     const unsigned gt = (unsigned)t * (NX + 1) * NU;
+    ldn<NU>(win.ubm, t * NU, o.ub);
+    ldn<NU>(Uk, t * NU, o.uk);
+    ldn<NU>(pin.stat, t * NU, o.st);
+    ldn<NU>(gains, gt + j * NU, o.Kx);
+    S kk[NU];
+    ldn<NU>(gains, gt + NX * NU, kk);
 #pragma unroll
-    for (int k = 0; k < NU; ++k) {
-      o.ub[k] = win.ubm.ld<double>(t * NU + k);
-      o.uk[k] = Uk.ld<double>(t * NU + k);
-      o.st[k] = pin.stat.template ld<double>(t * NU + k);
-      o.Kx[k] = gains.ld<S>(gt + j * NU + k);
-      o.kre[k] = real_of(gains.ld<S>(gt + NX * NU + k));
-    }
+    for (int k = 0; k < NU; ++k) o.kre[k] = real_of(kk[k]);
     return o;
   };
   auto step = [&](int t, const Ops& cur, Ops& nxt) __attribute__((always_inline)) {
@@ -1270,7 +1290,7 @@ __device__ __forceinline__ double rollout_policy(const Prov& prov, int T, S x0, 
     S ax, Brow[NU], dlt;
     prov.rows(cur.lin, x, ax, Brow, dlt);
     const S dx = csub(x, cur.xb);
-    cx += dot_re(dx, qrow_times<NX>(cost.q(t, T), dx, j));
+    cx += dot_re(dx, qrow_times<NX>(cost, t, T, dx, j));
     const S* Rt = cost.r(t);
     S xn = cadd(ax, dlt);
     double un[NU], eu[NU];
@@ -1313,10 +1333,7 @@ __device__ __forceinline__ double rollout_policy(const Prov& prov, int T, S x0, 
     x = xn;
     if (store_ok) {
       Xc.st<S>((t + 1) * NX + j, x);
-      if (j == 0) {
-#pragma unroll
-        for (int k = 0; k < NU; ++k) Uc.st<double>(t * NU + k, un[k]);
-      }
+      if (j == 0) stn<NU>(Uc, t * NU, un);
     }
   };
   Ops opsA = load(0), opsB;
@@ -1327,14 +1344,14 @@ __device__ __forceinline__ double rollout_policy(const Prov& prov, int T, S x0, 
   }
   if (t < T) step(t, opsA, opsB);
   const S e = csub(x, win.xbm.ld<S>(T * NX + j));
-  cx += dot_re(e, qrow_times<NX>(cost.q(T, T), e, j));
+  cx += dot_re(e, qrow_times<NX>(cost, T, T, e, j));
   return rowsum<NX>(cx) + cu;
 }
 
 // open-loop rollout of u = clip(U) (the starting point of a solve) with the objective of optimize.py:33-34,54;
 // writes the clipped controls and their trajectory to (Xc, Uc).
-template <class S, int NX, int NU, class Prov>
-__device__ __forceinline__ double rollout_open(const Prov& prov, int T, S x0, const Window& win, const CostRef<S>& cost,
+template <class S, int NX, int NU, class Prov, bool TR = false>
+__device__ __forceinline__ double rollout_open(const Prov& prov, int T, S x0, const Window& win, const CostRef<S, TR>& cost,
                                                const GView& U, const Box& box, const double (&lo0)[NU], const double (&hi0)[NU],
                                                const GView& Xc, const GView& Uc, int j, bool store_ok) {
   S x = x0;
@@ -1349,11 +1366,8 @@ __device__ __forceinline__ double rollout_open(const Prov& prov, int T, S x0, co
     Ops o;
     o.lin = prov.fetch(t);
     o.xb = win.xbm.ld<S>(t * NX + j);
-#pragma unroll
-    for (int k = 0; k < NU; ++k) {
-      o.ub[k] = win.ubm.ld<double>(t * NU + k);
-      o.uin[k] = U.ld<double>(t * NU + k);
-    }
+    ldn<NU>(win.ubm, t * NU, o.ub);
+    ldn<NU>(U, t * NU, o.uin);
     return o;
   };
   auto step = [&](int t, const Ops& cur, Ops& nxt) __attribute__((always_inline)) {
@@ -1362,7 +1376,7 @@ __device__ __forceinline__ double rollout_open(const Prov& prov, int T, S x0, co
     S ax, Brow[NU], dlt;
     prov.rows(cur.lin, x, ax, Brow, dlt);
     const S e = csub(x, cur.xb);
-    cx += dot_re(e, qrow_times<NX>(cost.q(t, T), e, j));
+    cx += dot_re(e, qrow_times<NX>(cost, t, T, e, j));
     const S* Rt = cost.r(t);
     double u[NU], eu[NU];
     S xn = cadd(ax, dlt);
@@ -1381,10 +1395,7 @@ __device__ __forceinline__ double rollout_open(const Prov& prov, int T, S x0, co
     x = xn;
     if (store_ok) {
       Xc.st<S>((t + 1) * NX + j, x);
-      if (j == 0) {
-#pragma unroll
-        for (int k = 0; k < NU; ++k) Uc.st<double>(t * NU + k, u[k]);
-      }
+      if (j == 0) stn<NU>(Uc, t * NU, u);
     }
   };
   Ops opsA = load(0), opsB;
@@ -1395,7 +1406,7 @@ __device__ __forceinline__ double rollout_open(const Prov& prov, int T, S x0, co
   }
   if (t < T) step(t, opsA, opsB);
   const S e = csub(x, win.xbm.ld<S>(T * NX + j));
-  cx += dot_re(e, qrow_times<NX>(cost.q(T, T), e, j));
+  cx += dot_re(e, qrow_times<NX>(cost, T, T, e, j));
   return rowsum<NX>(cx) + cu;
 }
 
@@ -1454,8 +1465,8 @@ constexpr int PDAS_CAP = M4Q_PDAS_CAP;
 
 // One iteration of the exact solve for the rows of the wavefront that have one in progress (r.busy()).  Returns true for
 // the rows whose solve ended in this call: r.Jk is then the objective of the answer, r.cur_is_a() says where it is.
-template <class S, int NX, int NU, class Prov>
-__device__ __forceinline__ bool box_qp_iterate(const Prov& prov, int T, S x0, const Window& win, const CostRef<S>& cost, int flags,
+template <class S, int NX, int NU, class Prov, bool TR = false>
+__device__ __forceinline__ bool box_qp_iterate(const Prov& prov, int T, S x0, const Window& win, const CostRef<S, TR>& cost, int flags,
                                                const GView& gains, PinCtx<NU>& pin, GView Xa, GView Ua, GView Xb, GView Ub,
                                                BoxQpRow& r, int j, int jj, bool lane_ok, PhaseClock* pc = nullptr) {
   PhaseClock none;
