@@ -256,7 +256,6 @@ struct m4q_session {
   bool force_complex = false;
   bool launched = false;        // a closed-loop launch has been enqueued since the watchdog flag was last read
   bool targ_const = false;      // every column of X_targ equals the first (per member, if per-member): xbar does not depend on t
-  bool utarg_const = false;     // ... and the same for U_targ
   bool use_real(bool diag) const {
     return !force_complex && diag && herm_ok[M4Q_F_MODELS] && herm_ok[M4Q_F_X0] && herm_ok[M4Q_F_X_TARG] &&
            herm_ok[M4Q_F_Q] && herm_ok[M4Q_F_QF] && herm_ok[M4Q_F_R];
@@ -531,15 +530,6 @@ int m4q_session_upload(m4q_session* s, int32_t field, const void* host, size_t b
         same = std::memcmp(ch + (it * cols + c) * n, ch + it * cols * n, 16 * n) == 0;
     s->targ_const = same;
   }
-  if (field == M4Q_F_U_TARG) {
-    const size_t cols = (size_t)s->prob.target_cols, items = cols ? bytes / (8 * m * cols) : 0;     // (stored with target_cols columns)
-    const double* uh = static_cast<const double*>(host);
-    bool same = cols > 0;
-    for (size_t it = 0; it < items && same; ++it)
-      for (size_t c = 1; c < cols && same; ++c)
-        same = std::memcmp(uh + (it * cols + c) * m, uh + it * cols * m, 8 * m) == 0;
-    s->utarg_const = same;
-  }
   if (!s->force_complex) {
     if (field == M4Q_F_MODELS) rc = lift_upload(s, field, ch, bytes / (16 * n * n * (1 + P)), true, (int)(1 + P), s->r_models);
     if (field == M4Q_F_X0) rc = lift_upload(s, field, ch, bytes / (16 * n), false, 1, s->r_x0);
@@ -649,7 +639,7 @@ int m4q_session_run(m4q_session* s, int32_t step_begin, int32_t step_end) {
   const size_t ns = path >= 2 ? n - 1 : n;         // dimension of the recursion
   m4q::MpcArgs a{};
   a.B = s->B; a.T = p.horizon; a.n_steps = p.n_steps; a.max_iter = p.max_iter; a.warm_start = p.warm_start;
-  a.flags = p.qp_flags | (s->targ_const ? 256 : 0) | (s->utarg_const ? 512 : 0);      // QP_TARG_CONST, QP_UTARG_CONST (csrc/m4q_mpc.h), internal
+  a.flags = p.qp_flags | (s->targ_const ? 256 : 0);      // 256 = QP_TARG_CONST (csrc/m4q_mpc.h), internal
   a.step_begin = step_begin; a.step_end = step_end;
   a.measure_freq = p.measure_freq > 1 ? p.measure_freq : 1;
   a.dt = p.dt; a.sat = p.sat; a.du = p.du; a.ls_tol = p.ls_tol;

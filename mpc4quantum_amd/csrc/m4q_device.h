@@ -74,7 +74,6 @@ __device__ __forceinline__ cplx csel(bool c, cplx a, cplx b) { return mk(c ? a.r
 #define M4Q_GLOBAL __attribute__((address_space(1)))
 #endif
 typedef double d2_t __attribute__((ext_vector_type(2)));
-typedef double d2u_t __attribute__((ext_vector_type(2), aligned(8)));     // the same 16 bytes at an 8-byte aligned address
 
 // loads / stores through global pointers (cplx travels as a 16-byte vector: one dwordx4 access)
 template <class T> struct GMem;
@@ -134,11 +133,6 @@ __device__ __forceinline__ void ldn(const GView& v, unsigned idx, double (&out)[
   if constexpr (N == 2) {
     const d2_t w = *reinterpret_cast<const M4Q_GLOBAL d2_t*>(v.base + (size_t)(v.off + idx * 8u));
     out[0] = w.x; out[1] = w.y;
-  } else if constexpr (N == 3) {
-    // (a 24-byte tuple is 8-byte aligned only: the pair goes as two dwords x 2 packed by hand - global accesses need dword alignment)
-    const d2u_t w = *reinterpret_cast<const M4Q_GLOBAL d2u_t*>(v.base + (size_t)(v.off + idx * 8u));
-    out[0] = w.x; out[1] = w.y;
-    out[2] = v.ld<double>(idx + 2);
   } else {
 #pragma unroll
     for (int k = 0; k < N; ++k) out[k] = v.ld<double>(idx + k);
@@ -149,10 +143,6 @@ __device__ __forceinline__ void stn(const GView& v, unsigned idx, const double (
   if constexpr (N == 2) {
     d2_t w; w.x = in[0]; w.y = in[1];
     *reinterpret_cast<M4Q_GLOBAL d2_t*>(v.base + (size_t)(v.off + idx * 8u)) = w;
-  } else if constexpr (N == 3) {
-    d2u_t w; w.x = in[0]; w.y = in[1];
-    *reinterpret_cast<M4Q_GLOBAL d2u_t*>(v.base + (size_t)(v.off + idx * 8u)) = w;
-    v.st<double>(idx + 2, in[2]);
   } else {
 #pragma unroll
     for (int k = 0; k < N; ++k) v.st<double>(idx + k, in[k]);

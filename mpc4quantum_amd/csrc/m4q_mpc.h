@@ -51,7 +51,6 @@ enum : int {
   QP_DU_BAND = 2,   // clip the first control to u_prev +- du as well (optimize.py:29-30)
   QP_EXACT_BOX = 4, // solve the box-constrained QP to optimality (projected Newton) instead of clipping the Riccati rollout
   QP_TARG_CONST = 256,   // internal (set by the host when every column of X_targ is the same): xbar_t does not depend on t
-  QP_UTARG_CONST = 512,  // internal (every column of U_targ the same): ubar_t does not depend on t - one load per sweep instead of one per index
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -714,9 +713,6 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
   S Pc[NX];
   S pv = zero_of<S>();
   S xb_next = win.xbm.ld<S>(T * NX + j);        // xbar_{t+1} of the first iteration
-  const bool uconst = (flags & QP_UTARG_CONST) != 0;
-  double ub0[NU];
-  ldn<NU>(win.ubm, 0, ub0);
   {
     const S* Qt = cost.q(T, T);
 #pragma unroll
@@ -736,9 +732,7 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
     o.lin = prov.fetch(t);
     if constexpr (TC) o.xb = xb_next;            // (constant target: the column loaded above serves every index)
     else o.xb = win.xbm.ld<S>(t * NX + j);
-#pragma unroll
-    for (int k = 0; k < NU; ++k) o.ub[k] = ub0[k];
-    if (!uconst) ldn<NU>(win.ubm, t * NU, o.ub);
+    ldn<NU>(win.ubm, t * NU, o.ub);
     if constexpr (PINNED) ldn<NU>(pin->stat, t * NU, o.stv);
     return o;
   };
@@ -1088,9 +1082,6 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
   const bool ref = (flags & QP_REF_LQR) != 0;
   const bool tconst = (flags & QP_TARG_CONST) != 0;          // xbar_t the same for every t: loaded once
   const S xb0 = win.xbm.ld<S>(j);
-  const bool uconst = (flags & QP_UTARG_CONST) != 0;
-  double ub0[NU];
-  ldn<NU>(win.ubm, 0, ub0);
   S x = x0;
   // destination views: lane offsets select between (Xo, Uo) and the shifted guess
   GView Xd = Xo, Ud = Uo;
@@ -1117,9 +1108,7 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
     o.xb = xb0;
     if (!tconst) o.xb = win.xbm.ld<S>(t * NX + j);
     const unsigned gt = (unsigned)t * (NX + 1) * NU;
-#pragma unroll
-    for (int k = 0; k < NU; ++k) o.ub[k] = ub0[k];
-    if (!uconst) ldn<NU>(win.ubm, t * NU, o.ub);
+    ldn<NU>(win.ubm, t * NU, o.ub);
     ldn<NU>(gains, gt + j * NU, o.Kx);
     S kk[NU];
     ldn<NU>(gains, gt + NX * NU, kk);
