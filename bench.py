@@ -351,13 +351,16 @@ def main():
     res = sess.results()
     units_per_step = int(res["qp_solves"].astype(np.int64).sum()) * T
     ok = int((res["exit_codes"] == 0).sum())
+    code_hist = [int((res["exit_codes"] == c).sum()) for c in range(4)]     # members by exit code (mpc.py:130): 0 done, 1 exit_condition,
+                                                                            # 2 the exact solver gave up, 3 non-finite
     info = sess.info()
     if multi:
         elapsed = float(comm.allreduce([elapsed], "max")[0])               # MAX over ranks of the timed region
-        tot = comm.allreduce([float(units_per_step), float(ok), 1.0], "sum")
+        tot = comm.allreduce([float(units_per_step), float(ok), 1.0] + [float(c) for c in code_hist], "sum")
         units_total = float(tot[0])
         ok_total = int(tot[1])
         joined = int(round(tot[2]))                                        # ranks the communicator really has
+        code_hist = [int(round(v)) for v in tot[3:7]]
     else:
         units_total = float(units_per_step)
         ok_total = ok
@@ -405,7 +408,7 @@ def main():
             "config": {"workload": "BASELINE config %d: d=%d (n=%d, m=%d), order %d, T=%d, n_steps=%d, %d ensemble members per GPU, "
                                    "per-instance models, full closed loop per step; %s arithmetic path (%s)" % (args.config, p["d"], n, m, p["order"], T, ns, B, path, detail),
                        "batch_per_gpu": B, "horizon": T, "n_steps": ns, "qp_solves_per_step": units_per_step // T,
-                       "instances_ok": ok_total, "parallelism": "ensemble-sharded x%d, one gather" % joined,
+                       "instances_ok": ok_total, "exit_codes": {str(c): code_hist[c] for c in range(4)}, "parallelism": "ensemble-sharded x%d, one gather" % joined,
                        "grid": info["grid"], "lds_bytes": info["lds_bytes"], "hbm_resident_bytes": info["hbm_bytes"],
                        **({"qp_mode": "exact box-constrained (active set on the Riccati factorisation)",
                            "exact_qp_stats": dict(zip(("qp_solves", "pinned_sweeps", "ratio_steps", "end_kkt", "end_precision",

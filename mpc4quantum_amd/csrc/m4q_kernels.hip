@@ -566,8 +566,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
         // (profiles/r03_phase_clock.txt: 3,060 cycles per index against 1,320)
         // (idle lanes sit it out as in the DPP kernels: MASK_IDLE itself is off for TILE because the tile sweep needs all 64 lanes)
         constexpr bool MASK_FWD = M4Q_MASK_IDLE && NS < 16;
-        if (!MASK_FWD || lane_ok)
-          chk = rollout_forward<S, NS, NU, false>(prov, T, x_cur, win, cost, flags, gains, sat, lo0, hi0, Xo, Uo, j, st, uapp, !use_ls, &Xg, &Ug);
+        if (!MASK_FWD || lane_ok)         // (the tile path runs with a constant target only)
+          chk = rollout_forward<S, NS, NU, false, true>(prov, T, x_cur, win, cost, flags, gains, sat, lo0, hi0, Xo, Uo, j, st, uapp, !use_ls, &Xg, &Ug);
         if constexpr (MASK_FWD) {
           chk = bcast<0>(chk);
 #pragma unroll
@@ -590,7 +590,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
         if (!tc && (!MASK_IDLE || lane_ok)) riccati_backward<S, NS, NU>(prov, T, win, cost, flags, gains, j, st);
         wave_sync();
         M4Q_PHASE_MARK(1)
-        if (!MASK_IDLE || lane_ok)
+        constexpr bool HAS_TCF = HAS_TC && M4Q_TCF(NS);
+        bool tcf = false;
+        if constexpr (HAS_TCF) tcf = tc;
+        if constexpr (HAS_TCF) {
+          if (tc && (!MASK_IDLE || lane_ok))
+            chk = rollout_forward<S, NS, NU, false, true>(prov, T, x_cur, win, cost, flags, gains, sat, lo0, hi0, Xo, Uo, j, st, uapp,
+                                                          !use_ls, &Xg, &Ug);
+        }
+        if (!tcf && (!MASK_IDLE || lane_ok))
           chk = rollout_forward<S, NS, NU, false>(prov, T, x_cur, win, cost, flags, gains, sat, lo0, hi0, Xo, Uo, j, st, uapp,
                                                   !use_ls, &Xg, &Ug);
         if constexpr (MASK_IDLE) {

@@ -39,6 +39,18 @@
 #ifndef M4Q_MASK_IDLE
 #define M4Q_MASK_IDLE 1      // lanes that own no column sit the two sweeps out (EXEC off): less power, higher clock (m4q_kernels.hip)
 #endif
+// Round 4: vector-memory instructions of the two sweeps (profiles/r04_ab_experiments.txt; every line an A/B on one box)
+#ifndef M4Q_TC_XB_ONCE
+#define M4Q_TC_XB_ONCE(n) ((n) < 15)  // constant-target backward sweep: xbar loaded once per sweep, not per index.  n = 15 (one wavefront
+                                      // per SIMD): the sweep WITHOUT that load is slower, 73.0 against 71.2 ms on config 4 - kept per index there
+#endif
+#ifndef M4Q_TCF
+#define M4Q_TCF(n) true               // constant-target instantiation of the rollout as well (xbar loaded once): config 3 35.77 -> 35.52 ms
+#endif
+#ifndef M4Q_STORE_ALL
+#define M4Q_STORE_ALL(n) true         // values replicated over a row (k, u) are stored by every lane of the row - no exec mask to set up -
+                                      // instead of by lane 0: config 4 75.5 -> 73.0 ms, config 3 together with M4Q_TC_XB_ONCE 36.05 -> 35.6
+#endif
 #ifndef M4Q_TARG_CONST
 #define M4Q_TARG_CONST 1     // constant targets: A_t xbar from 1 + NP products formed once per sweep
 #endif
@@ -730,7 +742,7 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
   auto load = [&](int t) __attribute__((always_inline)) {
     Ops o;
     o.lin = prov.fetch(t);
-    if constexpr (TC) o.xb = xb_next;            // (constant target: the column loaded above serves every index)
+    if constexpr (TC && M4Q_TC_XB_ONCE(NX)) o.xb = xb_next;            // (constant target: the column loaded above serves every index)
     else o.xb = win.xbm.ld<S>(t * NX + j);
     ldn<NU>(win.ubm, t * NU, o.ub);
     if constexpr (PINNED) ldn<NU>(pin->stat, t * NU, o.stv);
@@ -900,7 +912,7 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
     if (store_ok) {
       const unsigned gt = (unsigned)t * (NX + 1) * NU;
       stn<NU>(gains, gt + j * NU, Kst);
-      stn<NU>(gains, gt + NX * NU, kst);           // (replicated over the row: every lane writes the same bytes - no exec mask to set up)
+      if (M4Q_STORE_ALL(NX) || j == 0) stn<NU>(gains, gt + NX * NU, kst);   // (replicated over the row: every lane may write the same bytes)
     }
 
     // closed loop: Sx = A_t + B Kx (column j, in place): Ac[i] += lane_i(B[i][k]) Kx[k];  s = c + B k
@@ -1073,15 +1085,16 @@ __device__ __forceinline__ void adjoint_pass(const Prov& prov, int T, const Wind
 // step (alpha = 1, mpc.py:208-212) ends up with after its update and shift passes.  Safe in place: index
 // t of the guess has been read (one iteration ahead) before it is overwritten.
 // ---------------------------------------------------------------------------------------------
-template <class S, int NX, int NU, bool WANT_COST, class Prov, bool TR = false>
+// TCF: xbar_t is the same for every t (the caller has seen QP_TARG_CONST): one load per rollout instead of one per index.
+template <class S, int NX, int NU, bool WANT_COST, bool TCF = false, class Prov, bool TR = false>
 __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0, const Window& win, const CostRef<S, TR>& cost,
                                                    int flags, const GView& gains, double sat, const double (&lo0)[NU],
                                                    const double (&hi0)[NU], const GView& Xo, const GView& Uo, int j,
                                                    bool store_ok, double (&u_first)[NU], bool shift_out = false,
                                                    const GView* Xg = nullptr, const GView* Ug = nullptr) {
   const bool ref = (flags & QP_REF_LQR) != 0;
-  const bool tconst = (flags & QP_TARG_CONST) != 0;          // xbar_t the same for every t: loaded once
-  const S xb0 = win.xbm.ld<S>(j);
+  S xb0 = zero_of<S>();
+  if constexpr (TCF) xb0 = win.xbm.ld<S>(j);
   S x = x0;
   // destination views: lane offsets select between (Xo, Uo) and the shifted guess
   GView Xd = Xo, Ud = Uo;
@@ -1105,8 +1118,8 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
   auto load = [&](int t) __attribute__((always_inline)) {
     Ops o;
     o.lin = prov.fetch(t);
-    o.xb = xb0;
-    if (!tconst) o.xb = win.xbm.ld<S>(t * NX + j);
+    if constexpr (TCF) o.xb = xb0;
+    else o.xb = win.xbm.ld<S>(t * NX + j);
     const unsigned gt = (unsigned)t * (NX + 1) * NU;
     ldn<NU>(win.ubm, t * NU, o.ub);
     ldn<NU>(gains, gt + j * NU, o.Kx);
@@ -1172,10 +1185,10 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
       Xd.st<S>((t + xs_shift) * NX + j, x);
       // (u is replicated over the row: every lane writes the same bytes.  A shifting row's u_0 has no slot: it goes to slot 0,
       //  which the same lane's store of u_1 overwrites - no exec mask to set up)
-      stn<NU>(Ud, (unsigned)(t + us_shift > 0 ? t + us_shift : 0) * NU, u);
+      if (M4Q_STORE_ALL(NX) || j == 0) stn<NU>(Ud, (unsigned)(t + us_shift > 0 ? t + us_shift : 0) * NU, u);
       if (shift_out && t == T - 1) {
         Xd.st<S>(T * NX + j, x);                       // repeat the last column
-        stn<NU>(Ud, (T - 1) * NU, u);
+        if (M4Q_STORE_ALL(NX) || j == 0) stn<NU>(Ud, (T - 1) * NU, u);
       }
     }
     M4Q_PHASE();

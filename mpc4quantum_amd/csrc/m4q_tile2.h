@@ -62,11 +62,8 @@ struct TileBackwardG {
   };
   __device__ __forceinline__ Ops load(const Member& m, int t) const {
     Ops o;
-#pragma unroll
-    for (int s = 0; s < NU; ++s) {
-      o.ug[s] = m.Ug.template ld<double>(t * NU + s);
-      o.ub[s] = m.ubm.template ld<double>(t * NU + s);
-    }
+    ldn<NU>(m.Ug, t * NU, o.ug);                    // (one 16-byte access per pair, as the DPP sweeps: m4q_device.h ldn / stn)
+    ldn<NU>(m.ubm, t * NU, o.ub);
     ld_row(m.Xg, (unsigned)t * NS, o.xg);
     return o;
   }
@@ -247,17 +244,21 @@ struct TileBackwardG {
               Kr[g][s][J] = mm(H[g][J], cf[g][s], 0.0);
             }
           }
-      if (!(M4Q_T2_EXP & 2) && store_ok && L.r == 0) {
+      if (!(M4Q_T2_EXP & 2) && store_ok) {
+        // gains [t][col][s]: the m entries of a column are one tuple; Kc is replicated over r, kk over the member's 16 lanes: every
+        // lane stores (same bytes from the four r of a q) - no exec mask to set up
         const unsigned gt = (unsigned)t * (NS + 1) * NU;
 #pragma unroll
-        M4Q_G
+        M4Q_G {
 #pragma unroll
-          for (int s = 0; s < NU; ++s) {
+          for (int J = 0; J < NT; ++J) {
+            double kc[NU];
 #pragma unroll
-            for (int J = 0; J < NT; ++J)
-              if (4 * J + L.q < NS) mem[g].gains.template st<double>(gt + (4 * J + L.q) * NU + s, Kc[g][s][J]);
-            if (L.q == 0) mem[g].gains.template st<double>(gt + NS * NU + s, kk[g][s]);
+            for (int s = 0; s < NU; ++s) kc[s] = Kc[g][s][J];
+            if (NS % 4 == 0 || 4 * J + L.q < NS) stn<NU>(mem[g].gains, gt + (4 * J + L.q) * NU, kc);
           }
+          stn<NU>(mem[g].gains, gt + NS * NU, kk[g]);
+        }
       }
       double S[G][NT][NT], sv[G][NT], PS[G][NT][NT], w[G][NT];
 #pragma unroll
