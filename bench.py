@@ -241,6 +241,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="ensemble members per GPU (default: the config's own size)")
+    ap.add_argument("--order", type=int, default=1, help="order of the Taylor-truncated model (vectorize.py:8-49); 1 = the BASELINE configs'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cores", type=int, default=0, help="host cores for the CPU baseline (0 = all this job may use: affinity "
                                                              "mask cut to the cgroup CPU quota)")
@@ -285,7 +286,7 @@ def main():
     # every rank takes its own slice [rank*B, (rank+1)*B) of ONE world-sized ensemble draw (weak scaling);
     # per-member models are built on the device from the config's generators and scales
     full = args.batch or {1: 1, 2: 8192, 3: 65536, 4: 65536, 5: 2 ** 20}[args.config]
-    p = configs.build(args.config, batch=full, offset=rank * full, total=full * world, host_models=False)
+    p = configs.build(args.config, batch=full, order=args.order, offset=rank * full, total=full * world, host_models=False)
     B, n, m, T, ns = p["batch"], p["dim_x"], p["dim_u"], p["horizon"], p["n_steps"]
     P = _lib.lib().m4q_library_size(p["order"], m)
     per_model = p["scales"] is not None

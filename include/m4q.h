@@ -67,12 +67,16 @@ extern "C" {
  * recursion on the d*d - 1 traceless Hermitian coordinates - one dimension fewer, same results to rounding.  This bit keeps
  * such a session on the d*d-coordinate real path. */
 #define M4Q_OPT_NO_TRACELESS 2
-/* Experimental: a traceless session with a constant target over the horizon window runs the two sweeps of the clipped solve
- * on fp64 matrix-core tiles (v_mfma_f64_4x4x4_4b_f64, csrc/m4q_tile.h) instead of DPP rows - as built now the backward
- * sweep on tiles, the rollout on DPP rows.  Same results to rounding; on MI355X it is not faster than the DPP sweeps (config 3:
- * 41.9 against 41.5 ms; both sweeps on tiles 55 ms - dependent MFMA latency, profiles/r03_tile_log.txt), so it is off unless
- * this bit (or M4Q_TILE=1 in the environment) asks for it. */
+/* A traceless session with a constant target over the horizon window runs the BACKWARD sweep of the clipped solve on fp64
+ * matrix-core tiles (v_mfma_f64_4x4x4_4b_f64: one member per 16-lane block, its operands fetched four horizon indices at a time,
+ * csrc/m4q_tile3.h) and the rollout on DPP rows.  Same results to rounding.  Default where it is the faster form - d = 2 and d = 3
+ * (3 and 8 traceless coordinates: at d = 3 the DPP layout leaves half of every row idle) with an order-1 model: config 3
+ * 35.5 -> 32.2 ms, config 2 4.05 -> 2.9 ms, config 5's share 117.8 -> 104.4 ms (profiles/r04_ab_experiments.txt); at d = 4 the DPP
+ * rows are full and the tile form does not fit the register file (505 against 71 ms).
+ * M4Q_OPT_TILE (or M4Q_TILE=1 in the environment) asks for the tile sweep wherever it is built, M4Q_OPT_NO_TILE (or M4Q_NO_TILE=1)
+ * keeps a session on the DPP sweeps. */
 #define M4Q_OPT_TILE 4
+#define M4Q_OPT_NO_TILE 8
 
 /* exit codes per instance (mpc.py:130,195,202,291): 0 normal, 1 exit_condition (host side),
  * 2 solver gave up (mpc.py:183-197 turns a cvxpy/OSQP warning into this; here: an M4Q_QP_EXACT_BOX solve that stopped at
@@ -94,7 +98,7 @@ typedef struct m4q_problem {
   int32_t plant_per_instance;
   int32_t target_per_instance;
   int32_t target_cols; /* columns of X_targ; U_targ has the same count (extra ones unused) */
-  int32_t reserved;    /* options: M4Q_OPT_FORCE_COMPLEX | M4Q_OPT_NO_TRACELESS | M4Q_OPT_TILE */
+  int32_t reserved;    /* options: M4Q_OPT_FORCE_COMPLEX | M4Q_OPT_NO_TRACELESS | M4Q_OPT_TILE | M4Q_OPT_NO_TILE */
   int32_t measure_freq; /* StepClock.measure_freq (mpc.py:19,252-267): the plant is measured every measure_freq-th step, the
                            model closes the loop in between; 0 or 1 = every step */
   int32_t reserved2;

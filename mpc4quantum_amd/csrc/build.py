@@ -16,7 +16,7 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(PKG, "libm4q_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-command-line-argument"]
-HEADERS = ["m4q_device.h", "m4q_dpp_gen.h", "m4q_mpc.h", "m4q_tile.h", "m4q_args.h", "m4q_shapes.inc",
+HEADERS = ["m4q_device.h", "m4q_dpp_gen.h", "m4q_mpc.h", "m4q_tile.h", "m4q_tile2.h", "m4q_tile3.h", "m4q_args.h", "m4q_shapes.inc",
            os.path.join("..", "..", "include", "m4q.h")]
 STAMP = os.path.join(OBJ, "flags.stamp")       # the extra flags the objects in OBJ were built with
 

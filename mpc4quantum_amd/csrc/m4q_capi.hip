@@ -378,7 +378,13 @@ int m4q_session_create(const m4q_problem* p, int32_t B, int32_t device, m4q_sess
   // the grid (and the per-row workspace) is sized for whichever path keeps more workgroups resident
   const int exact = (p->qp_flags & M4Q_QP_EXACT_BOX) ? 1 : 0;
   int per_cu = std::max(sh->occupancy(p->plant_kind, 0, exact), s->force_complex ? 0 : sh->occupancy(p->plant_kind, 1, exact));
-  s->no_tile = !((p->reserved & M4Q_OPT_TILE) != 0 || std::getenv("M4Q_TILE") != nullptr);     // experimental: opt-in
+  // the tile form of the backward sweep: default at d = 2, 3 with an order-1 model (include/m4q.h: M4Q_OPT_TILE)
+  {
+    const bool want = (p->reserved & M4Q_OPT_TILE) != 0 || std::getenv("M4Q_TILE") != nullptr;
+    const bool refuse = (p->reserved & M4Q_OPT_NO_TILE) != 0 || std::getenv("M4Q_NO_TILE") != nullptr;
+    const bool dflt = sh->d >= 2 && sh->d <= 3 && p->order == 1;
+    s->no_tile = refuse || !(want || dflt);
+  }
   if (!s->force_complex && !s->no_traceless) per_cu = std::max(per_cu, sh->occupancy(p->plant_kind, 2, exact));
   if (!s->force_complex && !s->no_traceless && !s->no_tile && !exact) per_cu = std::max(per_cu, sh->occupancy(p->plant_kind, 3, 0));
   if (per_cu < 1) per_cu = 1;

@@ -6,7 +6,7 @@
 #define M4Q_KERNEL_TU 1
 #include "m4q_args.h"
 #include "m4q_mpc.h"
-#include "m4q_tile.h"
+#include "m4q_tile2.h"
 
 #ifndef M4Q_NX
 #error "compile with -DM4Q_NX -DM4Q_NU -DM4Q_ORDER"

@@ -48,7 +48,9 @@ __device__ __forceinline__ double mm(double x, double y, double c) { return __bu
 // per member 32 doubles and 4 words of LDS.
 constexpr int TILE_IO_DOUBLES = 32;     // [0, 16) x_cur | [16, 19) lo0 | [19, 22) hi0 | [22, 25) u_first | [25] chk | [26, 32) spare
 constexpr int TILE_IO_WORDS = 4;        // [0] flags (1 running, 2 shift_out) | [1] xbm byte offset | [2] ubm byte offset | [3] spare
-constexpr int TILE_GB_DOUBLES = 16;     // the G / h tile of one member
+constexpr int TILE_GB_DOUBLES = 18;     // the G / h tile of one member: 16 doubles at a pitch of 18 - every lane of a member reads the
+                                        // same entry, and at pitch 16 (128 bytes) members 0 / 2 and 1 / 3 read the same banks: 46 % of the
+                                        // tile kernel's LDS-active cycles were bank conflicts (gpurun_out/r04tile counters)
 constexpr int TILE_LDS_BYTES = 4 * (TILE_IO_DOUBLES * 8 + TILE_IO_WORDS * 4 + TILE_GB_DOUBLES * 8);
 
 template <int NS, int NU, int ORDER>
@@ -145,6 +147,7 @@ struct TileSweeps {
   // ---- backward Riccati sweep (lqr.py:28-65 with Delta and xbar_{t+1}); gains [t][col 0..NS][NU] -------------------------
   __device__ __forceinline__ void backward(bool store_ok) const {
     static_assert(ORDER != 1 || order1_is_identity<NU>(), "order-1 library must list u_1 .. u_m in order");
+    if constexpr (ORDER == 1) { backward_o1(store_ok); return; }      // (m4q_tile2.h: packed accesses, operands two indices ahead)
     // model tiles, natural
     double M[1 + NP][NT][NT];
 #pragma unroll
@@ -377,6 +380,8 @@ struct TileSweeps {
     for (int i = 0; i < PF - 1; ++i)
       if (t - i >= 0) step(t - i, ring[i]);
   }
+
+  __device__ __forceinline__ void backward_o1(bool store_ok) const;       // defined in m4q_tile2.h
 
   // ---- forward rollout with clipping (lqr.py:67-79; optimize.py:41); returns sum |x|^2 + sum u^2 (finite iff all are) -----
   // shift_out: the solution goes straight into the next step's (shifted) guess (mpc.py:271-272), see rollout_forward.

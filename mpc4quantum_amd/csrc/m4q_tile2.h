@@ -12,6 +12,7 @@
 // unless that measurement says it should.
 #pragma once
 #include "m4q_tile.h"
+#include "m4q_tile3.h"
 
 namespace m4q {
 
@@ -374,5 +375,33 @@ struct TileBackwardG {
   }
 #undef M4Q_G
 };
+
+// the order-1 backward sweep of m4q_tile.h's TileSweeps: the time-batched form of m4q_tile3.h (M4Q_TILE_BATCHED=0: this file's
+// per-index form with one group)
+#ifndef M4Q_TILE_BATCHED
+#define M4Q_TILE_BATCHED 1
+#endif
+template <int NS, int NU, int ORDER>
+__device__ __forceinline__ void TileSweeps<NS, NU, ORDER>::backward_o1(bool store_ok) const {
+  if constexpr (ORDER == 1) {
+#if M4Q_TILE_BATCHED
+    TileBackwardB<NS, NU, ORDER> tb;
+    tb.T = T;
+    tb.Q = Q; tb.Qf = Qf; tb.R = R;
+    tb.mdl = mdl;
+    tb.Xg = Xg; tb.Ug = Ug; tb.gains = gains; tb.xbm = xbm; tb.ubm = ubm;
+    tb.gb = gb;
+    tb.backward(store_ok);
+#else
+    TileBackwardG<NS, NU, ORDER, 1> tb;
+    tb.T = T;
+    tb.Q = Q; tb.Qf = Qf; tb.R = R;
+    tb.mem[0].mdl = mdl;
+    tb.mem[0].Xg = Xg; tb.mem[0].Ug = Ug; tb.mem[0].gains = gains; tb.mem[0].xbm = xbm; tb.mem[0].ubm = ubm;
+    tb.mem[0].gb = gb;
+    tb.backward(store_ok);
+#endif
+  }
+}
 
 }  // namespace m4q

@@ -233,7 +233,7 @@ class _HeldControl:
 
 def open_session(x0, models, dim_u, order, X_targ, U_targ, clock, plant_op0, plant_ops, Q, R, Qf, sat, du=None,
                  max_iter=100, warm_start=True, qp_flags=None, plant_kind=_lib.PLANT_HAMILTONIAN, device=-1,
-                 force_complex=False, exact_qp=False, traceless=True, tile=False):
+                 force_complex=False, exact_qp=False, traceless=True, tile=None):
     """An EnsembleSession loaded with mpc_batch's arguments (everything resident in HBM, nothing run yet)."""
     x0 = np.ascontiguousarray(x0, dtype=np.complex128)
     Bn, n = x0.shape
@@ -267,7 +267,7 @@ def open_session(x0, models, dim_u, order, X_targ, U_targ, clock, plant_op0, pla
 
 def mpc_batch(x0, models, dim_u, order, X_targ, U_targ, clock, plant_op0, plant_ops, Q, R, Qf, sat, du=None,
               max_iter=100, warm_start=True, qp_flags=None, plant_kind=_lib.PLANT_HAMILTONIAN, device=-1,
-              force_complex=False, exact_qp=False, traceless=True, tile=False):
+              force_complex=False, exact_qp=False, traceless=True, tile=None):
     """B independent closed loops in one launch.
     x0 [B, n]; models [B|1, n, n(1+P)]; X_targ (n, cols) / U_targ (m, cols) shared (or [B, ...] each);
     plant_op0 [B|1, k, k], plant_ops [B|1, m, k, k].  Returns a dict: xs [B, n, n_steps+1], us [B, m, n_steps]

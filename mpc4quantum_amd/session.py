@@ -18,7 +18,7 @@ class EnsembleSession:
     def __init__(self, B, dim_x, dim_u, order, horizon, n_steps, dt, sat, du=None, max_iter=100, warm_start=True,
                  qp_flags=None, plant_kind=_lib.PLANT_HAMILTONIAN, model_per_instance=False, plant_per_instance=False,
                  target_per_instance=False, target_cols=None, ls_tol=1e-4, device=-1, force_complex=False, measure_freq=1,
-                 exact_qp=False, traceless=True, tile=False):
+                 exact_qp=False, traceless=True, tile=None):
         """exact_qp: solve every QP of the loop to the box-constrained optimum (M4Q_QP_EXACT_BOX, what the reference's OSQP
         call converges to) instead of clipping the Riccati rollout."""
         if sat is None:
@@ -34,8 +34,10 @@ class EnsembleSession:
         p.target_per_instance = int(target_per_instance)
         p.target_cols = int(target_cols if target_cols is not None else n_steps + horizon + 1)
         # traceless=False keeps a real-path session on its d*d coordinates (M4Q_OPT_NO_TRACELESS) instead of the d*d - 1 traceless ones
+        # tile: None = the library's choice (the backward sweep on matrix-core tiles where that is the faster form: d = 2, 3 with an
+        # order-1 model and a constant target), True = wherever it is built (M4Q_OPT_TILE), False = DPP sweeps (M4Q_OPT_NO_TILE)
         p.reserved = (_lib.OPT_FORCE_COMPLEX if force_complex else 0) | (0 if traceless else _lib.OPT_NO_TRACELESS) | \
-            (_lib.OPT_TILE if tile else 0)
+            (0 if tile is None else (_lib.OPT_TILE if tile else _lib.OPT_NO_TILE))
         p.measure_freq = int(measure_freq)
         p.dt, p.sat, p.du, p.ls_tol = float(dt), float(sat), float(du if du is not None else 0.0), float(ls_tol)
         self.problem = p
@@ -127,7 +129,7 @@ class EnsembleSession:
 
     def path_detail(self):
         """'complex', 'real' (d*d Hermitian coordinates), 'traceless' (the d*d - 1 traceless Hermitian coordinates) or
-        'traceless-tile' (the same with the two sweeps of the clipped solve on fp64 matrix-core tiles)."""
+        'traceless-tile' (the same with the backward sweep of the clipped solve on fp64 matrix-core tiles)."""
         return ("complex", "real", "traceless", "traceless-tile")[_lib.check(self._L.m4q_session_path(self._h))]
 
     def info(self):

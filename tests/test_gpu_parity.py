@@ -668,13 +668,17 @@ def test_closed_loop_stepwise_teacher_forced(cfg, order, batch, horizon, path):
     QP-solve count - must match to 1e-10 whatever the conditioning of the loop; the shifted SQP
     guesses (the far end of a stiff 40-step horizon) to 1e-7.  horizon None = the BASELINE config's own size: every config
     runs at its own T (config 2: 20, configs 3 and 4: 40, config 5: 80) for all of its 20 MPC steps.
-    Paths: "real" = what a Liouvillian model gets by default (the d*d - 1 traceless Hermitian coordinates), "real9" = the d*d
-    Hermitian coordinates (M4Q_OPT_NO_TRACELESS), "tile" = traceless with the sweeps on matrix-core tiles (M4Q_OPT_TILE),
+    Paths: "real" = the d*d - 1 traceless Hermitian coordinates on DPP rows (M4Q_OPT_NO_TILE), "real9" = the d*d Hermitian
+    coordinates (M4Q_OPT_NO_TRACELESS), "tile" = traceless with the backward sweep on matrix-core tiles (what a Liouvillian
+    model with a constant target gets by default at d = 2, 3; M4Q_OPT_TILE at d = 4),
     "complex" = the general path.  A step may exceed the fixed bounds only by ten times what the ORACLE itself moves when the
     guess the step starts from is perturbed by 1e-15, and only if profiles/r04_parity_admissions.json lists that step for that
     case (_admit); config 3 order 1 (the headline) and configs 1, 2 admit nothing on any path."""
-    if path in ("real9", "tile") and (cfg, order, horizon) not in ((2, 1, None), (3, 1, None), (4, 1, 12)):
-        pytest.skip("the alternative real paths are exercised on one configuration per dimension")
+    if path == "real9" and (cfg, order, horizon) not in ((2, 1, None), (3, 1, None), (4, 1, 12)):
+        pytest.skip("the d*d-coordinate real path is exercised on one configuration per dimension")
+    if path == "tile" and not (order == 1 and (cfg in (1, 2, 3, 5) or (cfg, horizon) == (4, 12))):
+        pytest.skip("the tile sweep is the default at d = 2, 3 with an order-1 model (every such configuration runs it here); at "
+                    "d = 4 it is opt-in and exercised once")
     p = configs.build(cfg, batch=max(batch, 4) if cfg == 3 else batch, order=order, horizon=horizon)
     idx = np.arange(batch)
     trace = []
@@ -1216,7 +1220,7 @@ def test_properties_at_full_baseline_size(cfg, batch):
     assert np.abs(us).max() > 0.5 * p["sat"]                       # (and the ensemble is really being driven)
 
 
-@pytest.mark.parametrize("kw", [{}, {"exact_qp": True}, {"force_complex": True}, {"traceless": False}, {"tile": True}])
+@pytest.mark.parametrize("kw", [{}, {"tile": False}, {"exact_qp": True}, {"force_complex": True}, {"traceless": False}])
 def test_repeated_launches_are_bit_identical(kw):
     """Rows pull their work from a device-wide queue, heads and tails of a run may land on different workgroups, and in the
     exact mode a solve spans a varying number of passes: none of that may reach the numbers.  Four launches of the same
@@ -1250,7 +1254,8 @@ def test_repeated_launches_are_bit_identical(kw):
     for key in ("xs", "us", "qp_solves"):
         h.update(np.ascontiguousarray(first[key]).tobytes())
     name = "config3_B4096_" + ("exact" if kw.get("exact_qp") else "clip") + (
-        "_complex" if kw.get("force_complex") else "_real9" if kw.get("traceless") is False else "_tile" if kw.get("tile") else "_real")
+        "_complex" if kw.get("force_complex") else "_real9" if kw.get("traceless") is False else
+        "_real" if (kw.get("tile") is False or kw.get("exact_qp")) else "_tile")      # ({}: the default - backward sweep on tiles)
     store = os.environ.get("M4Q_STORE_CHECKSUMS")
     if store:
         have = json.load(open(store)) if os.path.exists(store) else {}
@@ -1515,12 +1520,18 @@ def test_arithmetic_path_selection():
             return sess.path_detail()
         finally:
             sess.close()
-    assert detail() == "traceless"
+    assert detail() == "traceless-tile"                               # d = 3, order 1, constant target: backward sweep on tiles
+    assert detail(tile=False) == "traceless"                          # M4Q_OPT_NO_TILE
     assert detail(tile=True) == "traceless-tile"
     assert detail(traceless=False) == "real"
     assert detail(qp_flags=_lib.QP_REF_LQR) == "real"
     assert detail(force_complex=True) == "complex"
-    assert detail(exact_qp=True, tile=True) == "traceless"            # the tile sweeps serve the clipped solve only
+    assert detail(exact_qp=True, tile=True) == "traceless"            # the tile sweep serves the clipped solve only
+    assert detail(exact_qp=True) == "traceless"
+
+    def ramped_target(q):                                             # a target that moves over the window: DPP sweeps
+        q["X_targ"] = q["X_targ"] * np.linspace(1.0, 1.0 - 1e-3, q["X_targ"].shape[1])[None, :]
+    assert detail(ramped_target) in ("traceless", "real")
 
     def half_trace_target(q):
         q["X_targ"] = 0.5 * q["X_targ"]

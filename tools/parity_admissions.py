@@ -2,7 +2,7 @@
 """Turn the admissions a GPU run recorded into the committed expectation the parity tests check against.
 
     M4Q_RECORD_ADMISSIONS=1 python -m pytest tests -m gpu -q          # on the GPU box: records, asserts nothing about the list
-    python tools/parity_admissions.py                                 # gpurun_out/parity_admissions_measured.json -> profiles/r04_parity_admissions.json
+    python tools/parity_admissions.py [--merge]                       # gpurun_out/parity_admissions_measured.json -> profiles/r04_parity_admissions.json
 
 A teacher-forced MPC step that misses the fixed parity bounds may pass on `tol + 10 x (what the ORACLE itself moves by under a
 1e-15 perturbation of the guess the step starts from)` only if this file lists that step for that case
@@ -16,8 +16,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
-    src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "parity_admissions_measured.json")
+    args = [a for a in sys.argv[1:] if a != "--merge"]
+    src = args[0] if args else os.path.join(ROOT, "gpurun_out", "parity_admissions_measured.json")
     recs = json.load(open(src))["admissions"]
+    dst = os.path.join(ROOT, "profiles", "r04_parity_admissions.json")
+    if "--merge" in sys.argv and os.path.exists(dst):
+        # a partial recording run (python -m pytest -k ...): cases it touched replace their records, the others keep theirs
+        seen = {r["case"] for r in recs}
+        recs = [r for r in json.load(open(dst))["measured"] if r["case"] not in seen] + recs
     allowed = {}
     for r in recs:
         allowed.setdefault(r["case"], [])
@@ -26,7 +32,6 @@ def main():
     out = {"note": "steps of the teacher-forced GPU parity tests that pass on the oracle-sensitivity clause instead of the fixed bounds; "
                    "every case not listed admits nothing (config 3 order 1 - the headline -, configs 1 and 2, every exact-mode case)",
            "allowed": {k: sorted(v) for k, v in sorted(allowed.items())}, "measured": recs}
-    dst = os.path.join(ROOT, "profiles", "r04_parity_admissions.json")
     with open(dst, "w") as f:
         json.dump(out, f, indent=1)
     print("%d admissions in %d cases -> %s" % (len(recs), len(allowed), dst))

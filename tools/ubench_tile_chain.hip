@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <vector>
 #include "m4q_tile2.h"
+#include "m4q_tile3.h"
 
 using namespace m4q;
 constexpr int NS = 8, NU = 2, ORDER = 1, NP = 2, PITCH = ModelPitch<NS>::value;
@@ -24,12 +25,15 @@ struct Args {
   const double* xbm;      // [T+1][NS] (constant target), shared
   const double* ubm;      // [T][NU], shared
   double* gains;          // [M][T][NS+1][NU]
+  unsigned long long* role_ticks;   // [2][2]: per role (0 tile / 1 dpp): sum of the wavefronts' 100 MHz ticks inside their sweeps, wavefront count
   int T, reps, members;   // members: total, a multiple of the members per wavefront
 };
 
 extern __shared__ __align__(16) unsigned char lds_raw[];
 
-template <int G, bool TILE, int WAVES, bool STORE = true>
+// MIX: wavefronts with an odd blockIdx run the DPP sweep, the even ones the tile sweep (G = 1): do the two forms disturb each other
+// when they share a SIMD, as a tile sweep and the DPP phases of the other wavefront do in the product's hybrid kernel?
+template <int G, bool TILE, int WAVES, bool STORE = true, bool MIX = false, bool BATCH = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k(Args a) {
   constexpr int MW = TILE ? 4 * G : 4;                       // members per wavefront
   double* lds = reinterpret_cast<double*>(lds_raw);
@@ -45,8 +49,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
   for (int e = lane; e < 2 * NS * NS + NU * NU; e += 64) ldsQ[e] = a.costs[e];
   __syncthreads();
   const int T = a.T;
+  const unsigned long long tick0 = __builtin_amdgcn_s_memrealtime();
+  const int role = (TILE && !(MIX && (blockIdx.x & 1))) ? 0 : 1;
   const unsigned sX = (unsigned)(T + 1) * NS, sU = (unsigned)T * NU, sG = (unsigned)T * (NS + 1) * NU;
-  if constexpr (TILE) {
+  if constexpr (BATCH) {                                     // m4q_tile3.h: time-batched operands, one group
+    TileBackwardB<NS, NU, ORDER> ts;
+    ts.T = T;
+    ts.Q = ldsQ; ts.Qf = ldsQ + NS * NS; ts.R = ldsQ + 2 * NS * NS;
+    const int mi = ts.L.mb;
+    ts.mdl = lds + mi * MODEL_K;
+    ts.Xg = gview((const M4Q_GLOBAL double*)a.Xg, m0 * sX, mi * sX);
+    ts.Ug = gview((const M4Q_GLOBAL double*)a.Ug, m0 * sU, mi * sU);
+    ts.gains = gview((const M4Q_GLOBAL double*)a.gains, m0 * sG, mi * sG);
+    ts.xbm = gview((const M4Q_GLOBAL double*)a.xbm, 0, 0);
+    ts.ubm = gview((const M4Q_GLOBAL double*)a.ubm, 0, 0);
+    ts.gb = gb + mi * 16;
+    for (int r = 0; r < a.reps; ++r) {
+      asm volatile("" ::: "memory");
+      ts.backward(STORE);
+    }
+  } else if (TILE && !(MIX && (blockIdx.x & 1))) {
     TileBackwardG<NS, NU, ORDER, G> ts;
     ts.T = T;
     ts.Q = ldsQ; ts.Qf = ldsQ + NS * NS; ts.R = ldsQ + 2 * NS * NS;
@@ -84,6 +106,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
       if (jj < NS) riccati_backward<double, NS, NU, FusedProv<double, NS, NU, ORDER>, false, true>(prov, T, win, cost, QP_TARG_CONST, gains, j, STORE);
     }
   }
+  if (threadIdx.x == 0) {
+    atomicAdd(a.role_ticks + 2 * role, __builtin_amdgcn_s_memrealtime() - tick0);
+    atomicAdd(a.role_ticks + 2 * role + 1, 1ull);
+  }
 }
 
 static double rnd(unsigned long long& h) {
@@ -91,27 +117,28 @@ static double rnd(unsigned long long& h) {
   return (double)(h >> 11) * (1.0 / 9007199254740992.0) - 0.5;
 }
 
-template <int G, bool TILE, int WAVES, bool STORE = true>
+template <int G, bool TILE, int WAVES, bool STORE = true, bool MIX = false, bool BATCH = false>
 static double run(const char* name, Args a, std::vector<double>* out_gains, const std::vector<double>* ref) {
   constexpr int MW = TILE ? 4 * G : 4;
   const size_t lds_need = sizeof(double) * (size_t)(MW * MODEL_K + 2 * NS * NS + NU * NU + MW * 16);
   // residency: exactly 4 * WAVES workgroups per CU (160 KB of LDS per CU)
   size_t lds = 160 * 1024 / (4 * WAVES) - 512;
   if (lds < lds_need) { printf("%-28s needs %zu B of LDS, %zu allowed at %d waves/SIMD: skipped\n", name, lds_need, lds, WAVES); return 0; }
-  hipFuncSetAttribute(reinterpret_cast<const void*>(k<G, TILE, WAVES, STORE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k<G, TILE, WAVES, STORE, MIX, BATCH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   int nb = 0;
-  hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k<G, TILE, WAVES, STORE>, 64, lds);
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k<G, TILE, WAVES, STORE, MIX, BATCH>, 64, lds);
   const int grid = 256 * 4 * WAVES * 2;                      // two rounds of the resident set
   hipMemset(a.gains, 0, sizeof(double) * (size_t)a.members * a.T * (NS + 1) * NU);
-  hipLaunchKernelGGL((k<G, TILE, WAVES, STORE>), dim3(grid), dim3(64), lds, 0, a);
+  hipLaunchKernelGGL((k<G, TILE, WAVES, STORE, MIX, BATCH>), dim3(grid), dim3(64), lds, 0, a);
   hipError_t e = hipDeviceSynchronize();
+  hipMemset(a.role_ticks, 0, 32);
   if (e != hipSuccess) { printf("%s: %s\n", name, hipGetErrorString(e)); exit(1); }
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   float best = 1e30f;
   for (int it = 0; it < 3; ++it) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL((k<G, TILE, WAVES, STORE>), dim3(grid), dim3(64), lds, 0, a);
+    hipLaunchKernelGGL((k<G, TILE, WAVES, STORE, MIX, BATCH>), dim3(grid), dim3(64), lds, 0, a);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
@@ -128,13 +155,22 @@ static double run(const char* name, Args a, std::vector<double>* out_gains, cons
   if (out_gains) *out_gains = h;
   printf("%-28s waves/SIMD %d (occupancy query: %d WG/CU)  %8.3f ms  %7.2f SIMD-ns per member-index", name, WAVES, nb, best, simd_ns);
   if (ref) printf("   max |gain - dpp gain| %.2e (of %.2e)", err, mag);
+  unsigned long long rt[4];
+  hipMemcpy(rt, a.role_ticks, 32, hipMemcpyDeviceToHost);
+  // mean wavefront time inside its sweeps, per role, as ns per wavefront-index (3 timed launches summed)
+  for (int r = 0; r < 2; ++r)
+    if (rt[2 * r + 1]) printf("   [%s wavefronts: %.0f ns per wavefront-index]", r ? "dpp" : "tile", 10.0 * rt[2 * r] / rt[2 * r + 1] / (a.T * a.reps));
   printf("\n");
   return simd_ns;
 }
 
-int main() {
-  const int T = 40, reps = 8;
-  const int members = 16 * 64;                              // distinct members; wavefronts wrap around them
+int main(int argc, char** argv) {
+  const int T = 40;
+  const int reps = (argc > 2) ? atoi(argv[2]) : 8;          // sweeps per wavefront: 8 = 1 ms launches; 400 = 50 ms (the clock settles under load)
+  // distinct members; wavefronts wrap around them.  Default 1,024: the operands (13.6 KB per member) stay in the L2.  `ubench_tile_chain big`:
+  // 32,768 members = 445 MB of trajectories and gains - every wavefront of the largest launch has its own, as in the product, where
+  // the per-row workspace comes from beyond the L2
+  const int members = (argc > 1) ? 32768 : 16 * 64;
   unsigned long long h = 12345;
   std::vector<double> models((size_t)members * 3 * 64), costs(132, 0.0), Xg((size_t)members * (T + 1) * NS), Ug((size_t)members * T * NU),
       xbm((T + 1) * NS), ubm(T * NU, 0.0);
@@ -159,6 +195,9 @@ int main() {
   hipMemcpy(dm, models.data(), models.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dc, costs.data(), costs.size() * 8, hipMemcpyHostToDevice);
   hipMemcpy(dx, Xg.data(), Xg.size() * 8, hipMemcpyHostToDevice); hipMemcpy(du, Ug.data(), Ug.size() * 8, hipMemcpyHostToDevice);
   hipMemcpy(dxb, xbm.data(), xbm.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dub, ubm.data(), ubm.size() * 8, hipMemcpyHostToDevice);
+  unsigned long long* drt;
+  hipMalloc(&drt, 32);
+  a.role_ticks = drt;
   a.models = dm; a.costs = dc; a.Xg = dx; a.Ug = du; a.xbm = dxb; a.ubm = dub; a.gains = dg; a.T = T; a.reps = reps; a.members = members;
   std::vector<double> ref;
 #if M4Q_T2_EXP
@@ -170,6 +209,9 @@ int main() {
   run<1, false, 2, false>("dpp rows, gains not stored", a, nullptr, nullptr);
   run<1, true, 2, false>("tile, G = 1, gains not stored", a, nullptr, nullptr);
   run<1, true, 2>("tile, G = 1 (m4q_tile.h form)", a, nullptr, &ref);
+  run<1, true, 2, true, false, true>("tile, time-batched operands", a, nullptr, &ref);
+  run<1, true, 1, true, false, true>("tile, time-batched operands", a, nullptr, &ref);
+  run<1, true, 2, true, true>("half tile, half dpp wavefronts", a, nullptr, &ref);
   run<1, true, 1>("tile, G = 1", a, nullptr, &ref);
   run<2, true, 1>("tile, G = 2", a, nullptr, &ref);
   run<2, true, 2>("tile, G = 2", a, nullptr, &ref);
