@@ -611,6 +611,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
         PinCtx<NU> pin;
         pin.stat = pin_stat;
         pin.box.sat = sat;
+        pin.tconst = (flags & QP_TARG_CONST) != 0;
 #pragma unroll
         for (int k = 0; k < NU; ++k) { pin.lo0[k] = lo0[k]; pin.hi0[k] = hi0[k]; }
         // rows starting a solve: the current SQP guess (the shifted previous solution on warm steps: nearly the right

@@ -702,6 +702,7 @@ struct PinCtx {
   // adjoint_pass (per row, `derive`): re-derives this row's working set from the gradient at the iterate (Xk, Uk) - the adjoint
   // recursion lam_t = Q e_t + A_t^H lam_{t+1}, g_t = R (u_t - ub_t) + Re B_t^H lam_{t+1}: a control is pinned iff it sits on a
   // bound with the gradient pushing outward.  nchg receives the number of entries that changed with respect to what `stat` held.
+  bool tconst = false;      // xbar_t is the same for every t (QP_TARG_CONST): the rollouts and the adjoint pass load it once
   bool derive = false;
   GView Xk, Uk;
   int nchg = 0;
@@ -1011,10 +1012,12 @@ __device__ __forceinline__ void adjoint_pass(const Prov& prov, int T, const Wind
     S xb, xk;
     double ub[NU], stv[NU], uk[NU];
   };
+  const S xb0 = win.xbm.ld<S>(j);
   auto load = [&](int t) __attribute__((always_inline)) {
     Ops o;
     o.lin = prov.fetch(t);
-    o.xb = win.xbm.ld<S>(t * NX + j);
+    o.xb = xb0;
+    if (!pin.tconst) o.xb = win.xbm.ld<S>(t * NX + j);
     o.xk = pin.Xk.template ld<S>(t * NX + j);
     ldn<NU>(win.ubm, t * NU, o.ub);
     ldn<NU>(pin.stat, t * NU, o.stv);
@@ -1271,10 +1274,12 @@ __device__ __forceinline__ double rollout_policy(const Prov& prov, int T, S x0, 
     S Kx[NU];
     double kre[NU];
   };
+  const S xb0 = win.xbm.ld<S>(j);
   auto load = [&](int t) __attribute__((always_inline)) {
     Ops o;
     o.lin = prov.fetch(t);
-    o.xb = win.xbm.ld<S>(t * NX + j);
+    o.xb = xb0;
+    if (!pin.tconst) o.xb = win.xbm.ld<S>(t * NX + j);
     const unsigned gt = (unsigned)t * (NX + 1) * NU;
     ldn<NU>(win.ubm, t * NU, o.ub);
     ldn<NU>(Uk, t * NU, o.uk);
