@@ -159,11 +159,10 @@ struct RowStash {
 // TL: the state lives in the NX - 1 traceless coordinates (S = double only; m4q_mpc.h).  NS = dimension of the recursion;
 // the I/O side (xs, the SQP-guess checkpoint, the plant) stays NX complex numbers per node.
 // TILE: the two sweeps of the clipped solve run on fp64 matrix-core tiles (m4q_tile.h) instead of DPP rows.
-#ifndef M4Q_TC_MIN_N
-#define M4Q_TC_MIN_N 8        // smallest recursion dimension that gets the constant-target instantiation of the sweep (round 2: 15 -
-                              // at d = 3 the second instantiation cost more in register allocation than it saved; with round 3's lower
-                              // pressure it pays: config 3 41.3 -> 40.3 ms, config 5's share 138.1 -> 134.7; d = 2 indifferent)
-#endif
+// smallest recursion dimension that gets the constant-target instantiation of the sweeps (round 2: 15 - at d = 3 the second
+// instantiation cost more in register allocation than it saved; with round 3's lower pressure it pays: config 3 41.3 -> 40.3 ms,
+// config 5's share 138.1 -> 134.7; d = 2 indifferent)
+constexpr int TC_MIN_N = 8;
 // EXACT: further cuts of an instance's run after step 2 (strictly increasing, > 2; see the kernel)
 #ifndef M4Q_EXACT_CUTS
 #define M4Q_EXACT_CUTS 5
@@ -175,9 +174,6 @@ constexpr int NXC = (int)(sizeof(XCUTS) / sizeof(int));
 #endif
 #ifndef M4Q_WAVES_TILE
 #define M4Q_WAVES_TILE 2
-#endif
-#ifndef M4Q_TILE_FORWARD
-#define M4Q_TILE_FORWARD 0      // the tile variant runs its BACKWARD sweep on matrix-core tiles and the rollout on DPP rows (1: both on tiles)
 #endif
 // Development builds (-DM4Q_DEV_PHASE_CLOCK): PhaseClock (m4q_device.h) sums the 100 MHz clock over the phases of the main loop; every
 // wavefront adds its sums to queue[8..23] (u64) on exit; M4Q_PHASE_TRACE=1 makes m4q_session_qp_stats print them.
@@ -529,39 +525,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
           ts.backward(run_t);
           wave_sync();
           M4Q_PHASE_MARK(1)
-#if M4Q_TILE_FORWARD
-          double x0t[TileSweeps<NS, NU, ORDER>::NT], lo_t[NU], hi_t[NU], uf[NU];
-#pragma unroll
-          for (int K = 0; K < TileSweeps<NS, NU, ORDER>::NT; ++K) {
-            const int e = 4 * K + ts.L.r;
-            const double v = tio[mb * TILE_IO_DOUBLES + (e < NS ? e : 0)];
-            x0t[K] = e < NS ? v : 0.0;
-          }
-#pragma unroll
-          for (int k = 0; k < NU; ++k) {
-            lo_t[k] = tio[mb * TILE_IO_DOUBLES + 16 + k];
-            hi_t[k] = tio[mb * TILE_IO_DOUBLES + 19 + k];
-            uf[k] = 0.0;
-          }
-          GView Xd = Xo, Ud = Uo;
-          Xd.off = (shift_t ? Xg.off : Xo.off) + (unsigned)(dm * (int)(sX * sizeof(double)));
-          Ud.off = (shift_t ? Ug.off : Uo.off) + (unsigned)(dm * (int)(sU * sizeof(double)));
-          const double ck = ts.forward(x0t, sat, lo_t, hi_t, Xd, Ud, shift_t, run_t, uf);
-          M4Q_PHASE_MARK(2)
-          if (ts.L.r == 0 && ts.L.q == 0) {
-#pragma unroll
-            for (int k = 0; k < NU; ++k) tio[mb * TILE_IO_DOUBLES + 22 + k] = uf[k];
-            tio[mb * TILE_IO_DOUBLES + 25] = ck;
-          }
-#endif
         }
         wave_sync();
-#if M4Q_TILE_FORWARD
-#pragma unroll
-        for (int k = 0; k < NU; ++k) uapp[k] = tio[g * TILE_IO_DOUBLES + 22 + k];
-        chk = tio[g * TILE_IO_DOUBLES + 25];
-        wave_sync();
-#else
         // the rollout on DPP rows: one short dependent chain per index, where the tile form waits on every operand
         // (profiles/r03_phase_clock.txt: 3,060 cycles per index against 1,320)
         // (idle lanes sit it out as in the DPP kernels: MASK_IDLE itself is off for TILE because the tile sweep needs all 64 lanes)
@@ -573,13 +538,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
 #pragma unroll
           for (int k = 0; k < NU; ++k) uapp[k] = bcast<0>(uapp[k]);
         }
-#endif
       } else if constexpr (!EXACT) {
         // (xbar_t the same for every t: the sweep needs no row form of A_t - wave-uniform choice between two instantiations.
         //  Round 2: n = 16 only - config 4 85.5 -> 84.2 ms, while at n = 9 the kernel with both instantiations was SLOWER, 50.65 -> 51.7 ms,
         //  although it executes 27 vector instructions fewer per horizon index (profiles/r02_ab_experiments.txt).  Round 3, with the
         //  kernel off the register ceiling: n >= 8 - M4Q_TC_MIN_N above.)
-        constexpr bool HAS_TC = M4Q_TARG_CONST && NS >= M4Q_TC_MIN_N && sizeof(S) == sizeof(double);
+        constexpr bool HAS_TC = NS >= TC_MIN_N && sizeof(S) == sizeof(double);
         bool tc = false;
         if constexpr (HAS_TC) tc = (flags & QP_TARG_CONST) != 0;
         if constexpr (HAS_TC) {

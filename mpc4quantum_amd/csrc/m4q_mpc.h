@@ -8,34 +8,18 @@
 #pragma once
 #include "m4q_device.h"
 
-// Tuning switches (defaults = what the A/B runs of profiles/r02_ab_experiments.txt selected; tools/build_variant.sh overrides)
-#ifndef M4Q_LDS_BATCH
-#define M4Q_LDS_BATCH 1      // real path, n <= 9: model read from LDS in one batch per horizon index (51.98 -> 50.38 ms)
-#endif
-#ifndef M4Q_HOIST_MODEL
-#define M4Q_HOIST_MODEL 1    // real path, n = 16: ROW form of the model in registers over a sweep (92.9 -> 85.8 ms; both forms: 87.5,
-                             // 209 spills; a per-index batch as for n <= 9: 92.9)
-#endif
-#ifndef M4Q_ADJ_HOIST_SMALL
-#define M4Q_ADJ_HOIST_SMALL 1   // exact mode's adjoint pass, n <= 9, order 1: N_p rows in registers, column form in one batch (226-229 -> 221-224 ms)
-#endif
-#ifndef M4Q_EXACT_TC
-#define M4Q_EXACT_TC 1          // exact mode: the pinned sweep's constant-target form with the same hoisted reads (config 3 exact 234-237 -> 222-224 ms)
-#endif
-#ifndef M4Q_BWD_QHOIST_LARGE
-#define M4Q_BWD_QHOIST_LARGE 1  // n = 16 (one wavefront per SIMD, 384 of 512 registers used): column j of Q held over the sweep, 72.2 -> 71.1 ms
-#endif
-#ifndef M4Q_BWD_HOIST_SMALL
-#define M4Q_BWD_HOIST_SMALL 1   // constant-target sweep, n <= 9: the N_p rows and column j of Q held in registers over the sweep, the column
-                                // form of the model read in one batch per index (round 3: 39.4 -> 38.6 -> 38.25 ms on config 3)
-#endif
-#ifndef M4Q_FWD_HOIST_SMALL
-#define M4Q_FWD_HOIST_SMALL 1   // rollout, n <= 9: the row form of the model held in registers over the rollout instead of one batch per index
-                                // (round 2, at the register ceiling: lost; round 3: 40.4 -> 39.4 ms on config 3.  The exact mode's rollouts: no gain.)
-#endif
-#ifndef M4Q_FWD_BATCH
-#define M4Q_FWD_BATCH 1      // rollout: the row form read in one batch (51.2 -> 50.85 ms)
-#endif
+// Settled by A/B runs and no longer switches (each was a macro until round 4; the losing branches are gone from the source, their
+// numbers are in profiles/r02_ab_experiments.txt, r03_exact_qp_log.txt, r04_ab_experiments.txt):
+//   real path, n <= 9: the model's column and row forms read from LDS in one batch per horizon index (51.98 -> 50.38 ms), in the
+//     rollout too (51.2 -> 50.85); with a constant target the N_p rows and column j of Q stay in registers over the sweep
+//     (39.4 -> 38.25 ms) and the row form over the rollout (40.4 -> 39.4);
+//   real path, n >= 15 (one wavefront per SIMD): the ROW form of the model and column j of Q in registers over a sweep
+//     (92.9 -> 85.8, 72.2 -> 71.1 ms); both forms (87.5 ms, 209 spills) and a per-index batch (92.9) lost;
+//   exact mode: the pinned sweep's constant-target form with the same hoisted reads (234 -> 222 ms), N_p rows in registers in the
+//     adjoint pass (226 -> 221);
+//   constant targets: A_t xbar from 1 + NP products formed once per sweep (recursions of dimension >= 8: 41.3 -> 40.3 ms);
+//   scheduling barriers between the phases of a sweep: slower (53.3 -> 52.5 ms without); the two-index form of the COMPLEX sweep:
+//     brings nothing and one experimental d = 4 build of it faulted - the complex sweep runs one index per trip.
 #ifndef M4Q_MASK_IDLE
 #define M4Q_MASK_IDLE 1      // lanes that own no column sit the two sweeps out (EXEC off): less power, higher clock (m4q_kernels.hip)
 #endif
@@ -50,9 +34,6 @@
 #ifndef M4Q_STORE_ALL
 #define M4Q_STORE_ALL(n) true         // values replicated over a row (k, u) are stored by every lane of the row - no exec mask to set up -
                                       // instead of by lane 0: config 4 75.5 -> 73.0 ms, config 3 together with M4Q_TC_XB_ONCE 36.05 -> 35.6
-#endif
-#ifndef M4Q_TARG_CONST
-#define M4Q_TARG_CONST 1     // constant targets: A_t xbar from 1 + NP products formed once per sweep
 #endif
 
 namespace m4q {
@@ -510,7 +491,7 @@ struct FusedProv {
     Poly<NU, ORDER> po;
     po.eval(l.u);
     S nx[NP];
-    if constexpr (M4Q_FWD_BATCH && sizeof(S) == sizeof(double) && batch_fits<NX, NU, ORDER>()) {
+    if constexpr (sizeof(S) == sizeof(double) && batch_fits<NX, NU, ORDER>()) {
       // as below with the (1 + NP) NX row elements read from LDS in one batch
       S row[1 + NP][NX];
 #pragma unroll
@@ -672,13 +653,6 @@ __device__ __forceinline__ S qrow_times(const CostRef<S, TR>& cost, int t, int T
 //   P  <- Q + Kx^H R Kx + Sx^H P Sx ;  p <- -Q r + Kx^H R k + Sx^H (P s + p)   lqr.py:64-65
 // gains layout: [t][col 0..NX][NU]  (col NX holds k); the view is positioned at the instance.
 // ---------------------------------------------------------------------------------------------
-// Phase marks of the sweeps.  -DM4Q_SCHED_PHASES turns them into scheduling barriers (an early build needed them against
-// spills; with today's statements the scheduler does better without: 53.3 -> 52.5 ms on config 3, d=4 7.92e8 -> 8.04e8).
-#ifdef M4Q_SCHED_PHASES
-#define M4Q_PHASE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define M4Q_PHASE() ((void)0)
-#endif
 // keeps loop-invariant LDS/global loads inside the horizon loops (hoisted, they cost hundreds of VGPRs)
 #define M4Q_NO_HOIST() asm volatile("" ::: "memory")
 
@@ -752,19 +726,19 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
   // n = 16 real path: one wavefront per SIMD owns all 512 registers, and alone on its SIMD it cannot hide the LDS
   // read-to-use latency of the model at every horizon index: the ROW form of the model is read once per sweep and kept in
   // registers (measured A/B on config 4: 92.9 -> 85.8 ms; profiles/r02_ab_experiments.txt)
-  constexpr bool HOIST_SMALL = M4Q_BWD_HOIST_SMALL && TC && (!PINNED || M4Q_EXACT_TC) && M4Q_HOIST_MODEL && sizeof(S) == sizeof(double) && NX < 15 &&
+  constexpr bool HOIST_SMALL = TC && sizeof(S) == sizeof(double) && NX < 15 &&
                                std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && batch_fits<NX, NU, Prov::ORDER_>();
-  constexpr bool HOIST = (M4Q_HOIST_MODEL && std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && sizeof(S) == sizeof(double) &&
+  constexpr bool HOIST = (std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && sizeof(S) == sizeof(double) &&
                           NX >= 15) || HOIST_SMALL;
   ModelRegs<S, NX, NU, Prov::ORDER_> mregs;
   if constexpr (HOIST) mregs.load_rows(prov.mdl, j);
   // constant target: real fused path with batched (n <= 9) or hoisted (n = 16, mode 2) model reads
   constexpr bool TCON = TC && std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && sizeof(S) == sizeof(double) &&
-                        ((M4Q_LDS_BATCH && batch_fits<NX, NU, Prov::ORDER_>()) || HOIST);
+                        ((batch_fits<NX, NU, Prov::ORDER_>()) || HOIST);
   S tterm[PowTab<NU, Prov::ORDER_>::NP + 1];
   if constexpr (TCON) prov.target_terms(xb_next, tterm);
   // the same family: column j of Q (the closed loop's stage cost does not change along the horizon) read once per sweep
-  constexpr bool QHOIST = (M4Q_BWD_HOIST_SMALL && HOIST_SMALL) || (M4Q_BWD_QHOIST_LARGE && HOIST && !PINNED);
+  constexpr bool QHOIST = (HOIST_SMALL) || (HOIST && !PINNED);
   S Qcol[NX];
   if constexpr (QHOIST) {
     const S* Q0 = cost.q(0, T);
@@ -793,14 +767,12 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
     } else if constexpr (HOIST) {
       prov.col(lin, Ac);
       prov.rows(mregs, lin, xb, ax, Brow, dlt);
-    } else if constexpr (M4Q_LDS_BATCH && sizeof(S) == sizeof(double) && batch_fits<NX, NU, Prov::ORDER_>()) {
+    } else if constexpr (sizeof(S) == sizeof(double) && batch_fits<NX, NU, Prov::ORDER_>()) {
       prov.col_rows(lin, xb, Ac, ax, Brow, dlt);
     } else {
       prov.col(lin, Ac);
-      M4Q_PHASE();
       prov.rows(lin, xb, ax, Brow, dlt);
     }
-    M4Q_PHASE();
 
     // affine column of the augmented dynamics
     S c = ax;
@@ -876,7 +848,6 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
       }
     }
     herm_inverse<NU>(g, ginv);
-    M4Q_PHASE();
     S Kx[NU], kk[NU];
 #pragma unroll
     for (int k = 0; k < NU; ++k) {
@@ -922,12 +893,10 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
     S s = c;
 #pragma unroll
     for (int k = 0; k < NU; ++k) cmac(s, Brow[k], kk[k]);
-    M4Q_PHASE();
 
     S PSc[NX];
     matmul_cols<NX>(PSc, Pc, Ac);                              // P Sx
     const S ws = dot_lane_index<false, true, NX>(s, Pc, pv);  // (P s + p)_j
-    M4Q_PHASE();
 
     S RK[NU], Rk[NU];
 #pragma unroll
@@ -953,31 +922,14 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
     if (ref) pn = csub(pn, qrow_times<NX>(Qt, xb, j));        // - Q xbar_t   (lqr.py:54-58)
     pv_out = pn;
     xb_next = xb;
-    M4Q_PHASE();
   };
   S Pd[NX];
   S pd = zero_of<S>();
   Ops opsA = load(T - 1), opsB;
-  // The two-index form is off for S = cplx.  It brings nothing there (the complex path is bound by FMA issue, not by the
-  // copies) and the d = 4 instantiation is BROKEN: built with -DM4Q_TWO_INDEX_COMPLEX=1 (tools/build_variant.sh), the first
-  // closed-loop launch of shape (16, 3, 1) aborted inside hipStreamSynchronize on one run and hung until my timeout killed it
-  // on the next (profiles/r02_two_index_complex_d4_fault.log) - corrupted control flow or addresses, not arithmetic.  Checked
-  // and ruled out: kernel resources (256 + 256 registers, 292 B/lane scratch, 154 SGPR spills: all next to the working
-  // one-index build's 244 B and 150), the > 64 KB dynamic-LDS attribute (same 77 KB in both), code size / long branches (137 KB,
-  // 5 s_getpc/s_setpc expansions, scratch SGPRs dead at every target; shipping kernels of 225 KB with the same expansions run),
-  // the trip logic and GView offsets (the same source runs as S = double on every shape).  What differs is register-file
-  // traffic at 100 % occupancy of the file: 651 v_accvgpr_read against 276.  Also ruled out on the disassembly: the three VGPRs that
-  // hold spilled SGPRs (v253-v255) are touched by v_writelane / v_readlane only - never copied to an AGPR or to scratch under a
-  // partial EXEC mask.  Later the same round, with the sweep's operand prefetch, the rollouts and the watchdog rewritten, the SAME
-  // variant build ran a staged probe (tests/probes/two_index_probe.py: one member / one step up to the faulting case) and 143 GPU
-  // tests without a fault, at the one-index build's speed (117.3 against 117.0 ms, config 4 complex, 16,384 members):
-  // profiles/r02_two_index_complex_d4_fault.log.  The fault is therefore not explained - a property of one build, not reproduced by
-  // the next - and the form stays off because it brings nothing.  Round 3: rebuilt once more from that round's source, probe and
-  // GPU tests under a 10 s watchdog, green again.
-#ifndef M4Q_TWO_INDEX_COMPLEX
-#define M4Q_TWO_INDEX_COMPLEX 0
-#endif
-  if constexpr (sizeof(S) == sizeof(double) || M4Q_TWO_INDEX_COMPLEX) {
+  // The two-index form serves S = double only: on the complex path it brings nothing (bound by FMA issue, not by the copies) and
+  // one experimental d = 4 build of it faulted in round 2 (closed in DESIGN.md 4.6: the faulting tree was never committed, rebuilds
+  // of the neighbouring commits pass a static audit and the GPU suite; the form is gone from the source).
+  if constexpr (sizeof(S) == sizeof(double)) {
     int t = T - 1;
     for (; t >= 1; t -= 2) {
       step(t, opsA, opsB, Pc, pv, Pd, pd);
@@ -1026,7 +978,7 @@ __device__ __forceinline__ void adjoint_pass(const Prov& prov, int T, const Wind
   };
   pin.nchg = 0;
   S lam = qrow_times<NX>(cost, T, T, csub(pin.Xk.template ld<S>(T * NX + j), win.xbm.ld<S>(T * NX + j)), j);
-  constexpr bool AHOIST = M4Q_ADJ_HOIST_SMALL && M4Q_HOIST_MODEL && std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value &&
+  constexpr bool AHOIST = std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value &&
                           sizeof(S) == sizeof(double) && batch_fits<NX, NU, Prov::ORDER_>() && Prov::ORDER_ == 1;
   ModelRegs<S, NX, NU, Prov::ORDER_> mregs;
   if constexpr (AHOIST) mregs.load_rows(prov.mdl, j);
@@ -1132,8 +1084,8 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
     for (int k = 0; k < NU; ++k) o.kre[k] = real_of(kk[k]);
     return o;
   };
-  constexpr bool HOIST = M4Q_HOIST_MODEL && std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && sizeof(S) == sizeof(double) &&
-                         (NX >= 15 || (M4Q_FWD_HOIST_SMALL && batch_fits<NX, NU, Prov::ORDER_>()));
+  constexpr bool HOIST = std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && sizeof(S) == sizeof(double) &&
+                         (NX >= 15 || (batch_fits<NX, NU, Prov::ORDER_>()));
   ModelRegs<S, NX, NU, Prov::ORDER_> mregs;
   if constexpr (HOIST) mregs.load_rows(prov.mdl, j);
   // one horizon index: `cur` holds its operands, those of the next index are fetched into `nxt` meanwhile.  The loop
@@ -1145,7 +1097,6 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
     S ax, Brow[NU], dlt;
     if constexpr (HOIST) prov.rows(mregs, cur.lin, x, ax, Brow, dlt);
     else prov.rows(cur.lin, x, ax, Brow, dlt);
-    M4Q_PHASE();
     const S dx = csub(x, cur.xb);
     double u[NU];
 #pragma unroll
@@ -1194,7 +1145,6 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
         if (M4Q_STORE_ALL(NX) || j == 0) stn<NU>(Ud, (T - 1) * NU, u);
       }
     }
-    M4Q_PHASE();
   };
 
   Ops opsA = load(0), opsB;
@@ -1520,7 +1470,6 @@ __device__ __forceinline__ bool box_qp_iterate(const Prov& prov, int T, S x0, co
     r.moved() = false;
     r.was_pdas() = r.pdas();
     if (r.going()) ++r.iters;
-#if M4Q_EXACT_TC
     // (constant target: the sweep's constant-target form, as in the clipped mode - a wave-uniform choice between two instantiations)
     if constexpr (sizeof(S) == sizeof(double) && NX >= 8) {
       if ((flags & QP_TARG_CONST) != 0) riccati_backward<S, NX, NU, Prov, true, true>(prov, Tf(), win, cost, flags, gains, j, r.going() && ok(), &pin);
@@ -1528,9 +1477,6 @@ __device__ __forceinline__ bool box_qp_iterate(const Prov& prov, int T, S x0, co
     } else {
       riccati_backward<S, NX, NU, Prov, true>(prov, Tf(), win, cost, flags, gains, j, r.going() && ok(), &pin);
     }
-#else
-    riccati_backward<S, NX, NU, Prov, true>(prov, Tf(), win, cost, flags, gains, j, r.going() && ok(), &pin);
-#endif
     wave_sync();
     settle();
     clk.mark(10);
