@@ -34,7 +34,7 @@ PEAK_F64_TFLOPS = 78.6      # MI355X fp64 dense rate (AMD spec; 256 CU x 4 SIMD 
                             # DPP row broadcasts) and v_mfma_f64 run on the SAME pipe at the same rate: tools/ubench_mfma.hip measures
                             # 76-78 TFLOP/s for either and the SUM when both are issued (profiles/r02_ubench_mfma.txt)
 PEAK_HBM_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md
-PMC_JSON = os.path.join(ROOT, "profiles", "r03_pmc.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r04_pmc.json")
 
 
 def mac_per_hstep(n, m, P):
@@ -67,12 +67,12 @@ def compulsory_bytes(B, n, m, P, T, ns, path):
 
 
 def pmc_record(key, avg_launch_ms):
-    """Counter record of this exact configuration from profiles/r02_pmc.json (tools/pmc_collect.py), or (None, why).  Refused when
+    """Counter record of this exact configuration from profiles/r04_pmc.json (tools/pmc_collect.py), or (None, why).  Refused when
     the launch it was taken on differs from the one measured now by more than 3 %: counters describe a binary, not a config."""
     try:
         rec = json.load(open(PMC_JSON))[key]
     except Exception:
-        return None, "no counter record for %s in profiles/r03_pmc.json" % key
+        return None, "no counter record for %s in profiles/r04_pmc.json" % key
     # like for like: the HIP-event launch time bench.py itself measured in the record's traced run (rocprofv3's own kernel-trace
     # average of that run, 1 % higher, is kept beside it and must agree: tests/test_bench_logic.py)
     ref = rec.get("hip_event_launch_ms_same_run") or rec.get("traced_avg_launch_ms") or 0.0
@@ -399,7 +399,7 @@ def main():
                          "fma_share_of_valu_insts": c["SQ_INSTS_VALU_FMA_F64"] / c["SQ_INSTS_VALU"] if "SQ_INSTS_VALU" in c else None,
                          "wave_time_waiting": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"] if "SQ_WAVE_CYCLES" in c else None,
                          "clock_ghz_under_load": cycles / (pmc_ms * 1e-3) / 1e9,
-                         "note": "from profiles/r03_pmc.json (separate --pmc passes on this binary); all 64 lanes counted"}
+                         "note": "from profiles/r04_pmc.json (separate --pmc passes on this binary); all 64 lanes counted"}
         out = {
             "metric": "MPC horizon-steps/sec across batch (3-level transmon, T=40)" if args.config == 3
                       else "MPC horizon-steps/sec across batch (config %d)" % args.config,
@@ -416,14 +416,16 @@ def main():
                                                        "end_cap"), qp_stats))} if qp_stats else {})},
             "roofline": {"bound": "valu_f64", "achieved": flops_exec / avg_launch_s / 1e12, "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s",
                          "frac": flops_exec / avg_launch_s / 1e12 / PEAK_F64_TFLOPS, "traffic": traffic,
-                         "kernel": "mpc_kernel<%s, PLANT_HAMILTONIAN, %s>" % ("double" if path == "real" else "cplx",
-                                                                              "true" if args.exact_qp else "false"),
+                         "kernel": "mpc_kernel<%s, PLANT_HAMILTONIAN, %s%s>" % (
+                             "double" if path == "real" else "cplx", "true" if args.exact_qp else "false",
+                             ", TL, TILE" if detail == "traceless-tile" else ", TL" if detail == "traceless" else ""),
                          "launches": launches, "avg_launch_ms": 1e3 * avg_launch_s,
                          "flop_per_horizon_step": executed_flop_per_hstep(n, m, P, detail, targ_const), "horizon_steps_per_launch": hsteps,
-                         "note": "compute-bound kernel: intensity >> the fp64 machine balance, so the binding roof is fp64 FMA issue "
-                                 "(v_fma_f64 with DPP row broadcasts; no MFMA instruction is executed - fp64 MFMA shares this pipe and "
-                                 "peak).  achieved = flops of the arithmetic the selected path EXECUTES (real path: a quarter of SURVEY "
-                                 "8d's complex-recursion count) / HIP-event launch time",
+                         "note": "compute-bound kernel: intensity >> the fp64 machine balance, so the binding roof is the fp64 pipe "
+                                 "(v_fma_f64 with DPP row broadcasts%s; fp64 MFMA and fp64 VALU share one pipe and one peak).  achieved = "
+                                 "flops of the recursion the selected path performs (real path: a quarter of SURVEY 8d's "
+                                 "complex-recursion count; products padded to 4 x 4 tiles are not counted twice) / HIP-event launch "
+                                 "time" % (", and - the backward sweep - v_mfma_f64_4x4x4_4b_f64 tiles" if detail == "traceless-tile" else ""),
                          "algorithmic_equivalent": {"achieved": flops_alg / avg_launch_s / 1e12, "unit": "TFLOP/s",
                                                     "note": "SURVEY 8d complex-recursion flops / time: a speed-up-adjusted throughput, "
                                                             "NOT a fraction of any roof (exceeds the peak on the real path at d=4)"},
@@ -431,7 +433,7 @@ def main():
                          "hbm": {"achieved": cbytes / avg_launch_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": cbytes / avg_launch_s / 1e9 / PEAK_HBM_GBS, "compulsory_bytes": cbytes,
                                  "note": "compulsory bytes of the persistent launch (models, states and guesses once per run)"},
-                         "traffic_note": why or "FETCH_SIZE/WRITE_SIZE of profiles/r03_pmc.json, taken on this binary (launch time "
+                         "traffic_note": why or "FETCH_SIZE/WRITE_SIZE of profiles/r04_pmc.json, taken on this binary (launch time "
                                                 "within 3 %): L2-miss bytes per launch, mostly served by the Infinity Cache"},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -69,12 +69,12 @@ extern "C" {
 #define M4Q_OPT_NO_TRACELESS 2
 /* A traceless session with a constant target over the horizon window runs the BACKWARD sweep of the clipped solve on fp64
  * matrix-core tiles (v_mfma_f64_4x4x4_4b_f64: one member per 16-lane block, its operands fetched four horizon indices at a time,
- * csrc/m4q_tile3.h) and the rollout on DPP rows.  Same results to rounding.  Default where it is the faster form - d = 2 and d = 3
- * (3 and 8 traceless coordinates: at d = 3 the DPP layout leaves half of every row idle) with an order-1 model: config 3
- * 35.5 -> 32.2 ms, config 2 4.05 -> 2.9 ms, config 5's share 117.8 -> 104.4 ms (profiles/r04_ab_experiments.txt); at d = 4 the DPP
- * rows are full and the tile form does not fit the register file (505 against 71 ms).
- * M4Q_OPT_TILE (or M4Q_TILE=1 in the environment) asks for the tile sweep wherever it is built, M4Q_OPT_NO_TILE (or M4Q_NO_TILE=1)
- * keeps a session on the DPP sweeps. */
+ * csrc/m4q_tile3.h) and the rollout on DPP rows, wherever that form is built: d = 2 and d = 3 (3 and 8 traceless coordinates: at
+ * d = 3 the DPP layout leaves half of every row idle) with an order-1 model.  Same results to rounding; config 3 35.5 -> 32.2 ms,
+ * config 2 4.05 -> 2.9 ms, config 5's share 117.8 -> 104.4 ms (profiles/r04_ab_experiments.txt).  At d = 4 the DPP rows are full
+ * and the tile form does not fit the register file (505 against 71 ms): not built.
+ * M4Q_OPT_NO_TILE (or M4Q_NO_TILE=1 in the environment) keeps a session on the DPP sweeps.  M4Q_OPT_TILE is accepted and ignored
+ * (round 3's opt-in bit: the tile sweep is no longer an option to ask for). */
 #define M4Q_OPT_TILE 4
 #define M4Q_OPT_NO_TILE 8
 

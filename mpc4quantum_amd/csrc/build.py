@@ -14,16 +14,19 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(PKG, "libm4q_hip.so")
+LIB_GEN = os.path.join(PKG, "libm4q_hip_gen.so")   # the closed-loop kernels with the generator plant (m4q_kernels.hip: M4Q_VARIANT_GEN)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-command-line-argument"]
-HEADERS = ["m4q_device.h", "m4q_dpp_gen.h", "m4q_mpc.h", "m4q_tile.h", "m4q_tile2.h", "m4q_tile3.h", "m4q_args.h", "m4q_shapes.inc",
+HEADERS = ["m4q_device.h", "m4q_dpp_gen.h", "m4q_mpc.h", "m4q_tile.h", "m4q_tile3.h", "m4q_args.h", "m4q_shapes.inc",
            os.path.join("..", "..", "include", "m4q.h")]
 STAMP = os.path.join(OBJ, "flags.stamp")       # the extra flags the objects in OBJ were built with
 
 
 def shapes():
+    """[(nx, nu, order, plant_only)] from m4q_shapes.inc."""
     txt = open(os.path.join(HERE, "m4q_shapes.inc")).read()
-    return [tuple(int(v) for v in m) for m in re.findall(r"^M4Q_SHAPE\((\d+),\s*(\d+),\s*(\d+)\)", txt, re.M)]
+    return [(int(a), int(b), int(c), "plant-only" in rest)
+            for a, b, c, rest in re.findall(r"^M4Q_SHAPE\((\d+),\s*(\d+),\s*(\d+)\)(.*)$", txt, re.M)]
 
 
 def stale(target, sources):
@@ -58,13 +61,20 @@ def build(force=False, jobs=None, extra=()):
         force = True
     jobs_list = []
     objs = []
-    for nx, nu, order in shapes():
+    gen_objs = []
+    for nx, nu, order, plant_only in shapes():
         obj = os.path.join(OBJ, "kernels_%d_%d_%d.o" % (nx, nu, order))
         objs.append(obj)
         src = os.path.join(HERE, "m4q_kernels.hip")
+        dims = ["-DM4Q_NX=%d" % nx, "-DM4Q_NU=%d" % nu, "-DM4Q_ORDER=%d" % order]
         if force or stale(obj, [src] + hdrs):
-            jobs_list.append([HIPCC] + COMMON + list(extra) + ["-DM4Q_NX=%d" % nx, "-DM4Q_NU=%d" % nu,
-                                                                "-DM4Q_ORDER=%d" % order, "-c", src, "-o", obj])
+            jobs_list.append([HIPCC] + COMMON + list(extra) + dims + (["-DM4Q_PLANT_ONLY"] if plant_only else []) + ["-c", src, "-o", obj])
+        d = {4: 2, 9: 3, 16: 4}.get(nx)
+        if d and not plant_only:                       # shapes with a device plant: their generator-plant closed-loop kernels
+            gobj = os.path.join(OBJ, "kernelsg_%d_%d_%d.o" % (nx, nu, order))
+            gen_objs.append(gobj)
+            if force or stale(gobj, [src] + hdrs):
+                jobs_list.append([HIPCC] + COMMON + list(extra) + dims + ["-DM4Q_VARIANT_GEN", "-c", src, "-o", gobj])
     capi = os.path.join(OBJ, "capi.o")
     objs.append(capi)
     src = os.path.join(HERE, "m4q_capi.hip")
@@ -75,6 +85,8 @@ def build(force=False, jobs=None, extra=()):
             list(ex.map(run, jobs_list))
     if force or jobs_list or stale(LIB, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    if force or jobs_list or stale(LIB_GEN, gen_objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_GEN] + gen_objs)
     with open(STAMP, "w") as f:
         f.write(want)
     return LIB

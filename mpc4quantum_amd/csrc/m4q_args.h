@@ -90,6 +90,8 @@ struct PlantArgs {
 // one entry per compiled (dim_x, dim_u, order)
 struct ShapeOps {
   int nx, nu, order, np, d;
+  int has_tile;                                                     // the tile form of the backward sweep is built for this shape (path 3)
+  int plant_only;                                                   // only plant_kernel is built (m4q_shapes.inc): serves m4q_plant_step_batch
   size_t (*mpc_lds_bytes)(int real_path, int exact_qp);
   int (*launch_mpc)(const MpcArgs&, int plant_kind, int real_path, int grid, hipStream_t);
   int (*launch_linearize)(const LinArgs&, hipStream_t);

@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -26,6 +27,8 @@ using m4q::cplx;
 #define M4Q_SHAPE(nx, nu, ord) extern "C" const m4q::ShapeOps* m4q_shape_##nx##_##nu##_##ord();
 #include "m4q_shapes.inc"
 #undef M4Q_SHAPE
+
+extern "C" __attribute__((visibility("hidden"))) void dim_d_anchor() {}      // an address inside this library, for dladdr
 
 namespace {
 
@@ -57,22 +60,55 @@ int fail(int code, const char* fmt, ...) {
     }                                                                                          \
   } while (0)
 
-const m4q::ShapeOps* find_shape(int nx, int nu, int order) {
+// plant_ok: plant-only shapes (m4q_shapes.inc) count too - for m4q_plant_step_batch; every other entry point needs the full set
+const m4q::ShapeOps* find_shape(int nx, int nu, int order, bool plant_ok = false) {
   static const m4q::ShapeOps* table[] = {
 #define M4Q_SHAPE(nx, nu, ord) m4q_shape_##nx##_##nu##_##ord(),
 #include "m4q_shapes.inc"
 #undef M4Q_SHAPE
   };
   for (const m4q::ShapeOps* s : table)
-    if (s->nx == nx && s->nu == nu && s->order == order) return s;
+    if (s->nx == nx && s->nu == nu && s->order == order && (plant_ok || !s->plant_only)) return s;
   return nullptr;
 }
 
 // any compiled order for (nx, nu): the QP and plant kernels do not depend on the library order
-const m4q::ShapeOps* find_shape_any_order(int nx, int nu) {
+const m4q::ShapeOps* find_shape_any_order(int nx, int nu, bool plant_ok = false) {
   for (int ord = 1; ord <= 3; ++ord)
-    if (const m4q::ShapeOps* s = find_shape(nx, nu, ord)) return s;
+    if (const m4q::ShapeOps* s = find_shape(nx, nu, ord, plant_ok)) return s;
   return nullptr;
+}
+
+// The closed-loop kernels with the GENERATOR plant live in a second library, libm4q_hip_gen.so, next to this one (M4Q_GEN_LIB
+// overrides the path): loaded the first time a session asks for that plant, never otherwise.  Returns the ops whose launch_mpc /
+// occupancy / mpc_lds_bytes serve such a session, or nullptr with the reason in `why`.
+const m4q::ShapeOps* gen_shape(int nx, int nu, int order, std::string& why) {
+  static std::mutex mu;
+  static void* handle = nullptr;
+  static std::string load_error;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!handle && load_error.empty()) {
+    std::string path;
+    if (const char* env = std::getenv("M4Q_GEN_LIB")) {
+      path = env;
+    } else {
+      Dl_info info{};
+      if (dladdr(reinterpret_cast<const void*>(&dim_d_anchor), &info) && info.dli_fname) {
+        path = info.dli_fname;
+        const size_t slash = path.find_last_of('/');
+        path = (slash == std::string::npos ? std::string() : path.substr(0, slash + 1)) + "libm4q_hip_gen.so";
+      }
+    }
+    handle = path.empty() ? nullptr : dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!handle) load_error = "the generator-plant kernels are in libm4q_hip_gen.so, which did not load (" + path + "): " + (dlerror() ? dlerror() : "?");
+  }
+  if (!handle) { why = load_error; return nullptr; }
+  char name[64];
+  snprintf(name, sizeof(name), "m4q_shapeg_%d_%d_%d", nx, nu, order);
+  typedef const m4q::ShapeOps* (*fn_t)();
+  fn_t fn = reinterpret_cast<fn_t>(dlsym(handle, name));
+  if (!fn) { why = std::string("libm4q_hip_gen.so has no ") + name; return nullptr; }
+  return fn();
 }
 
 int dim_d(int nx) { return nx == 4 ? 2 : nx == 9 ? 3 : nx == 16 ? 4 : 0; }
@@ -230,6 +266,7 @@ struct m4q_session {
   int B = 0;
   int device = 0;
   const m4q::ShapeOps* shape = nullptr;
+  const m4q::ShapeOps* mpc_ops = nullptr;      // launch_mpc / occupancy / mpc_lds_bytes: `shape`, or libm4q_hip_gen.so's for the generator plant
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int grid = 1;
@@ -338,6 +375,15 @@ int m4q_session_create(const m4q_problem* p, int32_t B, int32_t device, m4q_sess
   s->prob = *p;
   s->B = B;
   s->shape = sh;
+  s->mpc_ops = sh;
+  if (p->plant_kind == M4Q_PLANT_GENERATOR) {
+    std::string why;
+    s->mpc_ops = gen_shape(p->dim_x, p->dim_u, p->order, why);
+    if (!s->mpc_ops) {
+      delete s;
+      return fail(M4Q_E_UNSUPPORTED, "%s", why.c_str());
+    }
+  }
   s->force_complex = (p->reserved & 1) != 0 || std::getenv("M4Q_FORCE_COMPLEX") != nullptr || sh->d * sh->d != p->dim_x;
   // (M4Q_QP_REF_LQR builds its cost terms on xbar itself, lqr.py:54-58: the trace coordinate of the target does not drop out)
   s->no_traceless = (p->reserved & M4Q_OPT_NO_TRACELESS) != 0 || std::getenv("M4Q_NO_TRACELESS") != nullptr ||
@@ -377,16 +423,13 @@ int m4q_session_create(const m4q_problem* p, int32_t B, int32_t device, m4q_sess
   HIP_TRY_OWNED(s, hipGetDeviceProperties(&prop, s->device));
   // the grid (and the per-row workspace) is sized for whichever path keeps more workgroups resident
   const int exact = (p->qp_flags & M4Q_QP_EXACT_BOX) ? 1 : 0;
-  int per_cu = std::max(sh->occupancy(p->plant_kind, 0, exact), s->force_complex ? 0 : sh->occupancy(p->plant_kind, 1, exact));
-  // the tile form of the backward sweep: default at d = 2, 3 with an order-1 model (include/m4q.h: M4Q_OPT_TILE)
-  {
-    const bool want = (p->reserved & M4Q_OPT_TILE) != 0 || std::getenv("M4Q_TILE") != nullptr;
-    const bool refuse = (p->reserved & M4Q_OPT_NO_TILE) != 0 || std::getenv("M4Q_NO_TILE") != nullptr;
-    const bool dflt = sh->d >= 2 && sh->d <= 3 && p->order == 1;
-    s->no_tile = refuse || !(want || dflt);
-  }
-  if (!s->force_complex && !s->no_traceless) per_cu = std::max(per_cu, sh->occupancy(p->plant_kind, 2, exact));
-  if (!s->force_complex && !s->no_traceless && !s->no_tile && !exact) per_cu = std::max(per_cu, sh->occupancy(p->plant_kind, 3, 0));
+  const m4q::ShapeOps* mo = s->mpc_ops;
+  int per_cu = std::max(mo->occupancy(p->plant_kind, 0, exact), s->force_complex ? 0 : mo->occupancy(p->plant_kind, 1, exact));
+  // the tile form of the backward sweep is what a traceless session with a constant target runs wherever it is built (d = 2, 3 with an
+  // order-1 library: include/m4q.h, M4Q_OPT_NO_TILE)
+  s->no_tile = !sh->has_tile || (p->reserved & M4Q_OPT_NO_TILE) != 0 || std::getenv("M4Q_NO_TILE") != nullptr;
+  if (!s->force_complex && !s->no_traceless) per_cu = std::max(per_cu, mo->occupancy(p->plant_kind, 2, exact));
+  if (!s->force_complex && !s->no_traceless && !s->no_tile && !exact) per_cu = std::max(per_cu, mo->occupancy(p->plant_kind, 3, 0));
   if (per_cu < 1) per_cu = 1;
   if (const char* cap = std::getenv("M4Q_WGS_PER_CU")) {       // tuning experiments: fewer resident workgroups per CU
     const int v = std::atoi(cap);
@@ -707,7 +750,7 @@ int m4q_session_run(m4q_session* s, int32_t step_begin, int32_t step_end) {
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));
   HIP_TRY(hipEventRecord(e0, s->stream));
-  rc = s->shape->launch_mpc(a, p.plant_kind, path, s->grid, s->stream);
+  rc = s->mpc_ops->launch_mpc(a, p.plant_kind, path, s->grid, s->stream);
   if (rc) return fail(rc, "mpc kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));
   HIP_TRY(hipEventRecord(e1, s->stream));
   s->pending.emplace_back(e0, e1);
@@ -778,7 +821,7 @@ int m4q_session_info(const m4q_session* s, int64_t* hbm_bytes, int32_t* grid, in
   tot += (int64_t)(s->wsXg.bytes + s->wsUg.bytes + s->wsG.bytes);
   if (hbm_bytes) *hbm_bytes = tot;
   if (grid) *grid = s->grid;
-  if (lds_bytes) *lds_bytes = (int32_t)s->shape->mpc_lds_bytes(s->path(), (s->prob.qp_flags & M4Q_QP_EXACT_BOX) != 0);
+  if (lds_bytes) *lds_bytes = (int32_t)s->mpc_ops->mpc_lds_bytes(s->path(), (s->prob.qp_flags & M4Q_QP_EXACT_BOX) != 0);
   return 0;
 }
 
@@ -1015,7 +1058,7 @@ int m4q_session_build_models(m4q_session* s, double dt, const double* generators
 int m4q_plant_step_batch(int32_t B, int32_t dim_x, int32_t dim_u, int32_t plant_kind, double dt, const double* x,
                          const double* u, const double* op0, const double* ops, int32_t plant_per_instance,
                          double* x_next) {
-  const m4q::ShapeOps* sh = find_shape_any_order(dim_x, dim_u);
+  const m4q::ShapeOps* sh = find_shape_any_order(dim_x, dim_u, /*plant_ok=*/true);
   if (!sh) return fail(M4Q_E_UNSUPPORTED, "no kernel for dim_x=%d dim_u=%d", dim_x, dim_u);
   if (B <= 0 || !x || !u || !op0 || !ops || !x_next || (plant_kind != M4Q_PLANT_HAMILTONIAN && plant_kind != M4Q_PLANT_GENERATOR))
     return fail(M4Q_E_BADARG, "m4q_plant_step_batch: bad argument");

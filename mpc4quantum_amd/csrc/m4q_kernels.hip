@@ -6,10 +6,17 @@
 #define M4Q_KERNEL_TU 1
 #include "m4q_args.h"
 #include "m4q_mpc.h"
-#include "m4q_tile2.h"
+#include "m4q_tile3.h"
 
 #ifndef M4Q_NX
 #error "compile with -DM4Q_NX -DM4Q_NU -DM4Q_ORDER"
+#endif
+// Two objects per shape (build.py): the core object (libm4q_hip.so) holds every kernel except the closed-loop kernels with the
+// GENERATOR plant (x+ = expm(dt (L0 + sum u_k L_k)) x on n x n operators: QExperiment with collapse operators, LExperiment - outside
+// SURVEY section 8, and the largest objects of the library: up to 1 KB of scratch per lane); those are compiled with
+// -DM4Q_VARIANT_GEN into libm4q_hip_gen.so, which m4q_capi.hip loads on the first session that asks for that plant.
+#if defined(M4Q_PLANT_ONLY) || defined(M4Q_VARIANT_GEN)
+#define M4Q_NO_AUX 1
 #endif
 
 #define M4Q_CAT_(a, b, c, d) a##b##_##c##_##d
@@ -32,6 +39,10 @@ constexpr int MODEL_ELEMS = (1 + NP) * NX * PITCH;        // per instance, eleme
 // the traceless path (m4q_mpc.h) runs the recursion on NX - 1 coordinates; everything it stages is no larger than the above
 constexpr int SCRATCH_ELEMS = (SQUARE ? DD * DD : 0) + 2 * NX;   // plant / basis-change scratch per instance (complex)
 constexpr int ROWS = 4;                                    // instances per wavefront
+// the backward sweep on matrix-core tiles (m4q_tile3.h) is built where it is the faster form: d = 2, 3 (3 and 8 traceless coordinates)
+// with an order-1 library.  At d = 4 (15 coordinates = 4 x 4 tiles) it does not fit the register file (543 spilled VGPRs, 505 against
+// 71 ms on config 4) and full DPP rows leave nothing to gain; the host asks m4q_shape_*()->has_tile.
+constexpr bool HAS_TILE = SQUARE && ORDER == 1 && NX - 1 <= 8;
 
 // register budget: waves per SIMD the kernels are compiled for (512 / budget VGPRs per lane).  d = 2 was compiled for four until the
 // end of round 3: at 128 registers every d = 2 closed-loop kernel spilled (59-372 VGPRs), and its launches are chains of
@@ -187,7 +198,7 @@ constexpr int NXC = (int)(sizeof(XCUTS) / sizeof(int));
 template <class S, int PLANT, bool EXACT, bool TL = false, bool TILE = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_WAVES_TILE : EXACT ? M4Q_WAVES_EXACT(S) : WavesFor<S>::value, 8))) void mpc_kernel(MpcArgs) {
   static_assert(!TL || (sizeof(S) == sizeof(double) && SQUARE), "the traceless path is a real path of a d x d density matrix");
-  static_assert(!TILE || (TL && !EXACT), "tile sweeps: clipped solve on the traceless real coordinates");
+  static_assert(!TILE || (TL && !EXACT && ORDER == 1), "tile sweep: clipped solve on the traceless real coordinates, order-1 libraries");
   constexpr int NS = TL ? NX - 1 : NX;
   // LDS: [4 x scratch (complex)] [4 x model (S)] [Q Qf R (S)] [line-search weights] [watchdog deadline, row stash]
   cplx* scratch = reinterpret_cast<cplx*>(m4q_lds_raw);
@@ -209,9 +220,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
   stash.w = (volatile M4Q_LDS int*)(ldsW + WLS_DOUBLES + 1);
   stash.xm = stash_x_in_scratch<S>() ? (volatile M4Q_LDS double*)m4q_lds_raw : (volatile M4Q_LDS double*)(stash.w + ROWS * STASH_INTS);
   // TILE: hand-over block between the DPP-row state machine and the tile sweeps, and the G / h broadcast tiles
-  volatile M4Q_LDS double* tio = stash.xm + 64 * 2;
-  volatile M4Q_LDS int* tiw = (volatile M4Q_LDS int*)(tio + ROWS * TILE_IO_DOUBLES);
-  volatile M4Q_LDS double* tgb = (volatile M4Q_LDS double*)(tiw + ROWS * TILE_IO_WORDS);
+  volatile M4Q_LDS double* tgb = stash.xm + 64 * 2;
+  volatile M4Q_LDS int* tiw = (volatile M4Q_LDS int*)(tgb + ROWS * TILE_GB_DOUBLES);
   int T0, flags;
   bool ls_diag, two_phase;
   int n_pieces;                // work items per instance: head [step_begin, 2), then [2, XCUTS[0]), ... , [.., step_end)
@@ -496,17 +506,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
       const bool st = running && lane_ok;
       if constexpr (TILE) {
         // ---- hand the row's solve to the tile layout: member = (lane >> 2) & 3 there, lane >> 4 here ----
-        if (lane_ok) tio[g * TILE_IO_DOUBLES + jj] = real_of(x_cur);
         if (jj == 0) {
-#pragma unroll
-          for (int k = 0; k < NU; ++k) { tio[g * TILE_IO_DOUBLES + 16 + k] = lo0[k]; tio[g * TILE_IO_DOUBLES + 19 + k] = hi0[k]; }
-          tiw[g * TILE_IO_WORDS + 0] = (running ? 1 : 0) | (use_ls ? 0 : 2);
+          tiw[g * TILE_IO_WORDS + 0] = running ? 1 : 0;
           tiw[g * TILE_IO_WORDS + 1] = (int)win.xbm.off;
           tiw[g * TILE_IO_WORDS + 2] = (int)win.ubm.off;
         }
         wave_sync();
         {
-          TileSweeps<NS, NU, ORDER> ts;
+          TileBackwardB<NS, NU, ORDER> ts;
           const int mb = ts.L.mb;
           const int dm = mb - g;                                 // this lane's member there minus its member here
           ts.mdl = reinterpret_cast<const double*>(lds) + mb * MODEL_K;
@@ -520,15 +527,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
           ts.Q = reinterpret_cast<const double*>(cost.Q); ts.Qf = reinterpret_cast<const double*>(cost.Qf);
           ts.R = reinterpret_cast<const double*>(cost.R);
           ts.gb = tgb + mb * TILE_GB_DOUBLES;
-          const bool run_t = (tfl & 1) != 0, shift_t = (tfl & 2) != 0;
           M4Q_PHASE_MARK(3)
-          ts.backward(run_t);
+          ts.backward((tfl & 1) != 0);
           wave_sync();
           M4Q_PHASE_MARK(1)
         }
         wave_sync();
-        // the rollout on DPP rows: one short dependent chain per index, where the tile form waits on every operand
-        // (profiles/r03_phase_clock.txt: 3,060 cycles per index against 1,320)
+        // the rollout on DPP rows (a rollout on tiles was built in round 3 and lost: m4q_tile.h)
         // (idle lanes sit it out as in the DPP kernels: MASK_IDLE itself is off for TILE because the tile sweep needs all 64 lanes)
         constexpr bool MASK_FWD = M4Q_MASK_IDLE && NS < 16;
         if (!MASK_FWD || lane_ok)         // (the tile path runs with a constant target only)
@@ -887,6 +892,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
   }
 }
 
+#ifndef M4Q_NO_AUX          // (a plant-only shape - m4q_shapes.inc - builds plant_kernel alone; the generator-plant object none of these)
 // ---------------------------------------------------------------------------------------------
 // WrapModel.get_model_along_traj for B trajectories (linearize.py:61-70)
 // ---------------------------------------------------------------------------------------------
@@ -1012,6 +1018,9 @@ __global__ __launch_bounds__(64) M4Q_OCC void qp_kernel(QpArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 // One held-control plant step for B states (experiment.py:202-212)
+#endif  // M4Q_NO_AUX
+
+#ifndef M4Q_VARIANT_GEN
 // ---------------------------------------------------------------------------------------------
 template <int PLANT>
 __global__ __launch_bounds__(64) M4Q_OCC void plant_kernel(PlantArgs a) {
@@ -1044,6 +1053,8 @@ __global__ __launch_bounds__(64) M4Q_OCC void plant_kernel(PlantArgs a) {
 // discretize_homogeneous for B generator sets (vectorize.py:8-49): Taylor/Dyson expansion of
 // exp(dt (G_0 + sum_k u_k G_k)) to ORDER, every word of operators multiplied out and binned by its control
 // monomial.  One row per instance; generators staged in LDS, products column-owned in registers.
+#endif  // M4Q_VARIANT_GEN
+
 // ---------------------------------------------------------------------------------------------
 constexpr int find_monomial(int c0, int c1, int c2) {
   constexpr PowTab<NU, ORDER> tab{};
@@ -1131,7 +1142,7 @@ __global__ __launch_bounds__(64) void discretize_kernel(DiscArgs a) {
 // ---------------------------------------------------------------------------------------------
 static size_t mpc_lds_bytes(int path, int exact) {
   if constexpr (SQUARE) {
-    if (path == 3) return mpc_lds_layout_bytes<double, true, true>();
+    if constexpr (HAS_TILE) { if (path == 3) return mpc_lds_layout_bytes<double, true, true>(); }
     if (path == 2) return exact ? mpc_lds_layout_bytes<double, true, false, true>() : mpc_lds_layout_bytes<double, true, false>();
   }
   if (path) return exact ? mpc_lds_layout_bytes<double, false, false, true>() : mpc_lds_layout_bytes<double>();
@@ -1152,6 +1163,7 @@ struct LaunchOp {
   const MpcArgs& a;
   int grid;
   hipStream_t s;
+  int unsupported() const { return -(int)hipErrorInvalidValue; }
   template <class S, int PLANT, bool EXACT, bool TL, bool TILE>
   int run() const {
     const size_t lds = mpc_lds_layout_bytes<S, TL, TILE, EXACT>();
@@ -1162,6 +1174,7 @@ struct LaunchOp {
   }
 };
 struct OccupancyOp {
+  int unsupported() const { return 0; }
   template <class S, int PLANT, bool EXACT, bool TL, bool TILE>
   int run() const {
     int nb = 0;
@@ -1174,11 +1187,20 @@ struct OccupancyOp {
 template <class S, bool EXACT, bool TL, bool TILE, class Op>
 static int pick_plant(const Op& op, int plant_kind) {
   if constexpr (!SQUARE) {
+#ifdef M4Q_VARIANT_GEN
+    return op.unsupported();
+#else
     return op.template run<S, PLANT_NONE, EXACT, false, false>();
+#endif
   } else {
-    if (plant_kind == PLANT_HAMILTONIAN) return op.template run<S, PLANT_HAMILTONIAN, EXACT, TL, TILE>();
+#ifdef M4Q_VARIANT_GEN
     if (plant_kind == PLANT_GENERATOR) return op.template run<S, PLANT_GENERATOR, EXACT, TL, TILE>();
+    return op.unsupported();
+#else
+    if (plant_kind == PLANT_HAMILTONIAN) return op.template run<S, PLANT_HAMILTONIAN, EXACT, TL, TILE>();
+    if (plant_kind == PLANT_GENERATOR) return op.unsupported();          // (libm4q_hip_gen.so: the host routes such sessions there)
     return op.template run<S, PLANT_NONE, EXACT, TL, TILE>();
+#endif
   }
 }
 
@@ -1190,13 +1212,14 @@ static int pick_kernel(const Op& op, int plant_kind, int path, int exact, int un
     if (path || plant_kind != PLANT_NONE) return unsupported;
   }
   if constexpr (SQUARE) {
-    if (path == 3 && !exact) return pick_plant<double, false, true, true>(op, plant_kind);
+    if constexpr (HAS_TILE) { if (path == 3 && !exact) return pick_plant<double, false, true, true>(op, plant_kind); }
     if (path >= 2) return exact ? pick_plant<double, true, true, false>(op, plant_kind) : pick_plant<double, false, true, false>(op, plant_kind);
     if (path == 1) return exact ? pick_plant<double, true, false, false>(op, plant_kind) : pick_plant<double, false, false, false>(op, plant_kind);
   }
   return exact ? pick_plant<cplx, true, false, false>(op, plant_kind) : pick_plant<cplx, false, false, false>(op, plant_kind);
 }
 
+#ifndef M4Q_PLANT_ONLY
 static int launch_mpc(const MpcArgs& a, int plant_kind, int path, int grid, hipStream_t s) {
   return pick_kernel(LaunchOp{a, grid, s}, plant_kind, path, (a.flags & QP_EXACT_BOX) != 0, -(int)hipErrorInvalidValue);
 }
@@ -1205,11 +1228,17 @@ static int occupancy(int plant_kind, int path, int exact) {
   return pick_kernel(OccupancyOp{}, plant_kind, path, exact, 0);
 }
 
+#else
+static int launch_mpc(const MpcArgs&, int, int, int, hipStream_t) { return -(int)hipErrorInvalidValue; }
+static int occupancy(int, int, int) { return 0; }
+#endif
+
 static int grid_for(int B) {
   const int nquads = (B + ROWS - 1) / ROWS;
   return nquads < 4096 ? (nquads > 0 ? nquads : 1) : 4096;
 }
 
+#ifndef M4Q_NO_AUX
 static int launch_linearize(const LinArgs& a, hipStream_t s) {
   const size_t lds = sizeof(cplx) * (size_t)(ROWS * MODEL_ELEMS);
   int rc = prep_lds(linearize_kernel, lds);
@@ -1223,6 +1252,12 @@ static int launch_qp(const QpArgs& a, hipStream_t s) {
   return -(int)hipGetLastError();
 }
 
+#else
+static int launch_linearize(const LinArgs&, hipStream_t) { return -(int)hipErrorInvalidValue; }
+static int launch_qp(const QpArgs&, hipStream_t) { return -(int)hipErrorInvalidValue; }
+#endif
+
+#ifndef M4Q_VARIANT_GEN
 static int launch_plant(const PlantArgs& a, hipStream_t s) {
   if constexpr (!SQUARE) {
     return -(int)hipErrorInvalidValue;
@@ -1236,6 +1271,11 @@ static int launch_plant(const PlantArgs& a, hipStream_t s) {
   }
 }
 
+#else
+static int launch_plant(const PlantArgs&, hipStream_t) { return -(int)hipErrorInvalidValue; }
+#endif
+
+#ifndef M4Q_NO_AUX
 // path: 0 complex generators, 1 real n x n (lifted to the Hermitian basis), 2 real (n-1) x (n-1) (their traceless blocks)
 static int launch_discretize(const DiscArgs& a, int path, hipStream_t s) {
   if (!SQUARE && path) return -(int)hipErrorInvalidValue;
@@ -1251,6 +1291,10 @@ static int launch_discretize(const DiscArgs& a, int path, hipStream_t s) {
   return -(int)hipGetLastError();
 }
 
+#else
+static int launch_discretize(const DiscArgs&, int, hipStream_t) { return -(int)hipErrorInvalidValue; }
+#endif
+
 static int power_list(int32_t* out) {
   constexpr PowTab<NU, ORDER> tab{};
   for (int p = 0; p < PowTab<NU, ORDER>::COUNT; ++p)
@@ -1259,7 +1303,12 @@ static int power_list(int32_t* out) {
 }
 
 static const ShapeOps* shape_ops() {
-  static const ShapeOps ops = {NX, NU, ORDER, NP, DD, mpc_lds_bytes, launch_mpc, launch_linearize, launch_qp, launch_plant,
+#ifdef M4Q_PLANT_ONLY
+  constexpr int plant_only = 1;
+#else
+  constexpr int plant_only = 0;
+#endif
+  static const ShapeOps ops = {NX, NU, ORDER, NP, DD, HAS_TILE ? 1 : 0, plant_only, mpc_lds_bytes, launch_mpc, launch_linearize, launch_qp, launch_plant,
                                launch_discretize, power_list, occupancy};
   return &ops;
 }
@@ -1267,7 +1316,14 @@ static const ShapeOps* shape_ops() {
 }  // namespace shape_<nx>_<nu>_<order>
 }  // namespace m4q
 
-// registration symbol of this shape: m4q_shape_<nx>_<nu>_<order>
+// registration symbol of this shape: m4q_shape_<nx>_<nu>_<order> (linked into libm4q_hip.so), or - the generator-plant object -
+// m4q_shapeg_<nx>_<nu>_<order>, which libm4q_hip.so looks up in libm4q_hip_gen.so with dlsym
+#ifdef M4Q_VARIANT_GEN
+extern "C" __attribute__((visibility("default"))) const m4q::ShapeOps* M4Q_CAT(m4q_shapeg_, M4Q_NX, M4Q_NU, M4Q_ORDER)() {
+  return m4q::M4Q_CAT(shape_, M4Q_NX, M4Q_NU, M4Q_ORDER)::shape_ops();
+}
+#else
 extern "C" __attribute__((visibility("hidden"))) const m4q::ShapeOps* M4Q_CAT(m4q_shape_, M4Q_NX, M4Q_NU, M4Q_ORDER)() {
   return m4q::M4Q_CAT(shape_, M4Q_NX, M4Q_NU, M4Q_ORDER)::shape_ops();
 }
+#endif

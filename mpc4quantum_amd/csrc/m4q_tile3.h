@@ -1,6 +1,6 @@
 // m4q_tile3.h - the backward Riccati sweep on fp64 matrix-core tiles with TIME-BATCHED operands.
 //
-// What round 4's measurements said about the tile sweep of m4q_tile.h / m4q_tile2.h (profiles/r04_tile_chain.txt):
+// What round 4's measurements said about the tile sweep of round 3 (per-index operands; profiles/r04_tile_chain.txt):
 //   * in isolation it is 18-21 % faster than the DPP sweep (151 against 185 SIMD-ns per member-index), two interleaved groups per
 //     wavefront are NOT faster than one group in each of two wavefronts, and a tile wavefront does not suffer from a DPP wavefront
 //     on its SIMD;

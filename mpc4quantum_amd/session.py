@@ -34,10 +34,10 @@ class EnsembleSession:
         p.target_per_instance = int(target_per_instance)
         p.target_cols = int(target_cols if target_cols is not None else n_steps + horizon + 1)
         # traceless=False keeps a real-path session on its d*d coordinates (M4Q_OPT_NO_TRACELESS) instead of the d*d - 1 traceless ones
-        # tile: None = the library's choice (the backward sweep on matrix-core tiles where that is the faster form: d = 2, 3 with an
-        # order-1 model and a constant target), True = wherever it is built (M4Q_OPT_TILE), False = DPP sweeps (M4Q_OPT_NO_TILE)
+        # tile: None / True = the library's choice (the backward sweep on matrix-core tiles where that form is built: d = 2, 3 with an
+        # order-1 model, whenever the target is constant over the window), False = DPP sweeps (M4Q_OPT_NO_TILE)
         p.reserved = (_lib.OPT_FORCE_COMPLEX if force_complex else 0) | (0 if traceless else _lib.OPT_NO_TRACELESS) | \
-            (0 if tile is None else (_lib.OPT_TILE if tile else _lib.OPT_NO_TILE))
+            (_lib.OPT_NO_TILE if tile is False else 0)
         p.measure_freq = int(measure_freq)
         p.dt, p.sat, p.du, p.ls_tol = float(dt), float(sat), float(du if du is not None else 0.0), float(ls_tol)
         self.problem = p

@@ -670,15 +670,14 @@ def test_closed_loop_stepwise_teacher_forced(cfg, order, batch, horizon, path):
     runs at its own T (config 2: 20, configs 3 and 4: 40, config 5: 80) for all of its 20 MPC steps.
     Paths: "real" = the d*d - 1 traceless Hermitian coordinates on DPP rows (M4Q_OPT_NO_TILE), "real9" = the d*d Hermitian
     coordinates (M4Q_OPT_NO_TRACELESS), "tile" = traceless with the backward sweep on matrix-core tiles (what a Liouvillian
-    model with a constant target gets by default at d = 2, 3; M4Q_OPT_TILE at d = 4),
+    model with a constant target gets by default at d = 2, 3),
     "complex" = the general path.  A step may exceed the fixed bounds only by ten times what the ORACLE itself moves when the
     guess the step starts from is perturbed by 1e-15, and only if profiles/r04_parity_admissions.json lists that step for that
     case (_admit); config 3 order 1 (the headline) and configs 1, 2 admit nothing on any path."""
     if path == "real9" and (cfg, order, horizon) not in ((2, 1, None), (3, 1, None), (4, 1, 12)):
         pytest.skip("the d*d-coordinate real path is exercised on one configuration per dimension")
-    if path == "tile" and not (order == 1 and (cfg in (1, 2, 3, 5) or (cfg, horizon) == (4, 12))):
-        pytest.skip("the tile sweep is the default at d = 2, 3 with an order-1 model (every such configuration runs it here); at "
-                    "d = 4 it is opt-in and exercised once")
+    if path == "tile" and not (order == 1 and cfg in (1, 2, 3, 5)):
+        pytest.skip("the tile sweep exists at d = 2, 3 with an order-1 model (every such configuration runs it here)")
     p = configs.build(cfg, batch=max(batch, 4) if cfg == 3 else batch, order=order, horizon=horizon)
     idx = np.arange(batch)
     trace = []

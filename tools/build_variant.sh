@@ -17,8 +17,9 @@ pids=""
 for s in $all; do
   if echo " $shapes " | grep -q " $s "; then
     IFS=_ read nx nu ord <<< "$s"
+    po=""; grep -q "^M4Q_SHAPE($nx, *$nu, *$ord).*plant-only" $src/m4q_shapes.inc && po="-DM4Q_PLANT_ONLY"
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-command-line-argument \
-        -DM4Q_DEV -DM4Q_NX=$nx -DM4Q_NU=$nu -DM4Q_ORDER=$ord "$@" -c $src/m4q_kernels.hip -o $out/kernels_$s.o &
+        -DM4Q_DEV -DM4Q_NX=$nx -DM4Q_NU=$nu -DM4Q_ORDER=$ord $po "$@" -c $src/m4q_kernels.hip -o $out/kernels_$s.o &
     pids="$pids $!"
     objs="$objs $out/kernels_$s.o"
   else

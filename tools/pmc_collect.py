@@ -49,7 +49,7 @@ def bench_line(log):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tag", default="r03")
+    ap.add_argument("--tag", default="r04")
     ap.add_argument("--config", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--exact-qp", action="store_true")
@@ -89,6 +89,12 @@ def main():
     b = traced or line
     key = "config%d_B%d_%s_%s" % (a.config, b["config"]["batch_per_gpu"], "real" if b["dtype"] == "f64" else "complex",
                                   "exact" if a.exact_qp else "clip")
+    # (the same suffixes bench.py appends: which real path ran)
+    wl = b["config"]["workload"]
+    if wl.endswith("(real)"):
+        key += "_real9"
+    if wl.endswith("(traceless-tile)"):
+        key += "_tile"
     stats_ms = None
     for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
         rows = list(csv.DictReader(open(f)))

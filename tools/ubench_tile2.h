@@ -8,10 +8,9 @@
 // arithmetic, same lane map, same operand layout as m4q_tile.h (read its header first); group g's member mb is member 4 g + mb of
 // the wavefront.
 //
-// Measured in isolation by tools/ubench_tile_chain.hip (profiles/r04_tile_chain.txt); the closed-loop kernel does not use it
-// unless that measurement says it should.
+// Measured in isolation by tools/ubench_tile_chain.hip (profiles/r04_tile_chain.txt): two groups in one wavefront are slower than one
+// group in each of two wavefronts.  A measurement harness, not product code: the closed-loop kernel runs csrc/m4q_tile3.h.
 #pragma once
-#include "m4q_tile.h"
 #include "m4q_tile3.h"
 
 namespace m4q {
@@ -375,33 +374,5 @@ struct TileBackwardG {
   }
 #undef M4Q_G
 };
-
-// the order-1 backward sweep of m4q_tile.h's TileSweeps: the time-batched form of m4q_tile3.h (M4Q_TILE_BATCHED=0: this file's
-// per-index form with one group)
-#ifndef M4Q_TILE_BATCHED
-#define M4Q_TILE_BATCHED 1
-#endif
-template <int NS, int NU, int ORDER>
-__device__ __forceinline__ void TileSweeps<NS, NU, ORDER>::backward_o1(bool store_ok) const {
-  if constexpr (ORDER == 1) {
-#if M4Q_TILE_BATCHED
-    TileBackwardB<NS, NU, ORDER> tb;
-    tb.T = T;
-    tb.Q = Q; tb.Qf = Qf; tb.R = R;
-    tb.mdl = mdl;
-    tb.Xg = Xg; tb.Ug = Ug; tb.gains = gains; tb.xbm = xbm; tb.ubm = ubm;
-    tb.gb = gb;
-    tb.backward(store_ok);
-#else
-    TileBackwardG<NS, NU, ORDER, 1> tb;
-    tb.T = T;
-    tb.Q = Q; tb.Qf = Qf; tb.R = R;
-    tb.mem[0].mdl = mdl;
-    tb.mem[0].Xg = Xg; tb.mem[0].Ug = Ug; tb.mem[0].gains = gains; tb.mem[0].xbm = xbm; tb.mem[0].ubm = ubm;
-    tb.mem[0].gb = gb;
-    tb.backward(store_ok);
-#endif
-  }
-}
 
 }  // namespace m4q

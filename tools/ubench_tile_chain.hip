@@ -1,17 +1,17 @@
 // Microbenchmark for VERDICT r3 item 3: the backward Riccati sweep of BASELINE config 3's shape (8 traceless coordinates, 2
 // controls, order 1, T = 40, constant target) in isolation - no state machine, no rollout - in three forms:
 //   dpp     riccati_backward<double, 8, 2, ..., TC> on DPP rows, 4 members per wavefront (what the product's headline kernel runs)
-//   tile G  m4q_tile2.h: the same sweep on v_mfma_f64_4x4x4_4b_f64 tiles with G groups of 4 members interleaved per wavefront
+//   tile G  tools/ubench_tile2.h: the same sweep on v_mfma_f64_4x4x4_4b_f64 tiles with G groups of 4 members interleaved per wavefront
 // at W wavefronts per SIMD (residency forced with an LDS pad).  Prints SIMD-nanoseconds per member-index (lower = better; the
 // whole chip: 1024 SIMDs) and checks the tile forms' gains against the DPP form's.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I mpc4quantum_amd/csrc tools/ubench_tile_chain.hip -o tools/bin/ubench_tile_chain
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I mpc4quantum_amd/csrc -I tools tools/ubench_tile_chain.hip -o tools/bin/ubench_tile_chain
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "m4q_tile2.h"
 #include "m4q_tile3.h"
+#include "ubench_tile2.h"
 
 using namespace m4q;
 constexpr int NS = 8, NU = 2, ORDER = 1, NP = 2, PITCH = ModelPitch<NS>::value;
