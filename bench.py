@@ -394,7 +394,10 @@ def main():
                 cycles = c["GRBM_GUI_ACTIVE"] / 8.0                       # shader cycles of the counted launch (sum over 8 XCDs)
                 slots = 1024 * cycles / 4.0                               # fp64 FMA wave-instruction slots: 1024 SIMDs, 4 cycles each
                 pmc_ms = sum(rec["pmc_pass_launch_ms"]) / len(rec["pmc_pass_launch_ms"])
+                mfma = c.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0)           # one per v_mfma_f64_4x4x4_4b_f64 (16.7 cycles of the same pipe)
                 issue = {"fma_f64_wave_insts": c["SQ_INSTS_VALU_FMA_F64"], "frac_of_fma_issue_slots": c["SQ_INSTS_VALU_FMA_F64"] / slots,
+                         "mfma_f64_wave_insts": mfma,
+                         "frac_of_fp64_pipe_cycles": (4.0 * c["SQ_INSTS_VALU_FMA_F64"] + 16.7 * mfma) / (1024 * cycles),
                          "valu_busy": c["SQ_ACTIVE_INST_VALU"] / slots if "SQ_ACTIVE_INST_VALU" in c else None,
                          "fma_share_of_valu_insts": c["SQ_INSTS_VALU_FMA_F64"] / c["SQ_INSTS_VALU"] if "SQ_INSTS_VALU" in c else None,
                          "wave_time_waiting": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"] if "SQ_WAVE_CYCLES" in c else None,

@@ -48,14 +48,24 @@ def test_counter_records_are_refused_when_stale(tmp_path, monkeypatch):
 
 
 def test_committed_counter_records_cover_every_baseline_config():
-    recs = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc.json")))
-    for key in ("config2_B8192_real_clip", "config3_B65536_real_clip", "config3_B65536_complex_clip", "config3_B65536_real_exact",
-                "config4_B65536_real_clip", "config5_B131072_real_clip"):
+    recs = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc.json")))
+    # (d = 2, 3 run their backward sweep on matrix-core tiles: key suffix _tile, MFMA instructions counted; d = 4, the complex path,
+    #  the exact mode and the DPP sweeps kept for comparison execute none)
+    for key, tile in (("config2_B8192_real_clip_tile", True), ("config3_B65536_real_clip_tile", True), ("config3_B65536_real_clip", False),
+                      ("config3_B65536_complex_clip", False), ("config3_B65536_real_exact", False), ("config4_B65536_real_clip", False),
+                      ("config5_B131072_real_clip_tile", True)):
         r = recs[key]
         assert r["traced_avg_launch_ms"] > 0 and r["counters"]["SQ_INSTS_VALU_FMA_F64"] > 0
-        assert r["counters"]["SQ_INSTS_VALU_MFMA_MOPS_F64"] == 0            # no MFMA instruction in any of the default kernels
+        assert (r["counters"]["SQ_INSTS_VALU_MFMA_MOPS_F64"] > 0) == tile
         # the HIP-event time of bench.py and rocprofv3's kernel-trace average of the same run agree
         assert abs(r["hip_event_launch_ms_same_run"] - r["traced_avg_launch_ms"]) <= 0.02 * r["traced_avg_launch_ms"]
+    # the headline's record: v_mfma_f64_4x4x4_4b_f64 at 44 per wavefront and horizon index (4 members), and fewer vector instructions than
+    # the DPP sweeps need for the same work
+    t, d = recs["config3_B65536_real_clip_tile"], recs["config3_B65536_real_clip"]
+    per_index = t["counters"]["SQ_INSTS_VALU_MFMA_MOPS_F64"] / (t["horizon_steps_per_launch"] / 4.0)
+    assert 40 <= per_index <= 48
+    assert t["counters"]["SQ_INSTS_VALU"] < 0.65 * d["counters"]["SQ_INSTS_VALU"]
+    assert t["traced_avg_launch_ms"] < 0.95 * d["traced_avg_launch_ms"]
 
 
 def test_usable_cores_is_positive_and_bounded():
