@@ -17,10 +17,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--minutes", type=float, default=8.0)
 ap.add_argument("--batch", type=int, default=16384)
 a = ap.parse_args()
-MODES = [("config3 real", 3, {}), ("config3 complex", 3, {"force_complex": True}), ("config3 exact real", 3, {"exact_qp": True}),
+MODES = [("config3 real (tile sweep: default)", 3, {}), ("config3 complex", 3, {"force_complex": True}), ("config3 exact real", 3, {"exact_qp": True}),
          ("config3 exact complex", 3, {"exact_qp": True, "force_complex": True}), ("config4 real", 4, {}),
          ("config4 complex", 4, {"force_complex": True}), ("config2 real", 2, {}), ("config5 real (T=80)", 5, {}),
-         ("config3 real, 9 coordinates", 3, {"traceless": False}), ("config3 tile sweeps", 3, {"tile": True}),
+         ("config3 real, 9 coordinates", 3, {"traceless": False}), ("config3 real, DPP sweeps", 3, {"tile": False}),
          ("config4 exact real", 4, {"exact_qp": True}), ("config2 exact real", 2, {"exact_qp": True})]
 sessions = []
 for name, cfg, kw in MODES:
@@ -58,5 +58,5 @@ while time.time() - t0 < 60 * a.minutes:
     rounds += 1
     print("round %d: %d launches, all bit-identical to their first (%.0f s)" % (rounds, launches, time.time() - t0), flush=True)
 for name, d in first.items():
-    print("%-24s %s" % (name, d))
+    print("%-36s %s" % (name, d))
 print("soak ok: %d rounds, %d launches, %d modes" % (rounds, launches, len(MODES)))
