@@ -73,8 +73,10 @@ extern "C" {
  * d = 3 the DPP layout leaves half of every row idle) with an order-1 model.  Same results to rounding; config 3 35.5 -> 32.2 ms,
  * config 2 4.05 -> 2.9 ms, config 5's share 117.8 -> 104.4 ms (profiles/r04_ab_experiments.txt).  At d = 4 the DPP rows are full
  * and the tile form does not fit the register file (505 against 71 ms): not built.
- * M4Q_OPT_NO_TILE (or M4Q_NO_TILE=1 in the environment) keeps a session on the DPP sweeps.  M4Q_OPT_TILE is accepted and ignored
- * (round 3's opt-in bit: the tile sweep is no longer an option to ask for). */
+ * The same holds for the pinned sweep of an M4Q_QP_EXACT_BOX solve (its time-batched tile form: config 3 exact 208 -> 190 ms).
+ * M4Q_OPT_NO_TILE (or M4Q_NO_TILE=1 in the environment) keeps a session on the DPP sweeps (exact mode: the DPP pinned sweep for
+ * general targets, which that kernel holds anyway).  M4Q_OPT_TILE is accepted and ignored (round 3's opt-in bit: the tile sweep is
+ * no longer an option to ask for). */
 #define M4Q_OPT_TILE 4
 #define M4Q_OPT_NO_TILE 8
 

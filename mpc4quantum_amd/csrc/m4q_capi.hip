@@ -688,7 +688,7 @@ int m4q_session_run(m4q_session* s, int32_t step_begin, int32_t step_end) {
   const size_t ns = path >= 2 ? n - 1 : n;         // dimension of the recursion
   m4q::MpcArgs a{};
   a.B = s->B; a.T = p.horizon; a.n_steps = p.n_steps; a.max_iter = p.max_iter; a.warm_start = p.warm_start;
-  a.flags = p.qp_flags | (s->targ_const ? 256 : 0);      // 256 = QP_TARG_CONST (csrc/m4q_mpc.h), internal
+  a.flags = p.qp_flags | (s->targ_const ? 256 : 0) | (s->no_tile ? 512 : 0);      // QP_TARG_CONST, QP_NO_TILE (csrc/m4q_mpc.h), internal
   a.step_begin = step_begin; a.step_end = step_end;
   a.measure_freq = p.measure_freq > 1 ? p.measure_freq : 1;
   a.dt = p.dt; a.sat = p.sat; a.du = p.du; a.ls_tol = p.ls_tol;

@@ -126,12 +126,15 @@ template <int N> constexpr int cost_elems() { return 2 * N * N + NU * NU; }
 // Transposed copies of Q and Qf behind the costs (CostRef<S, TR>, m4q_mpc.h): the exact mode on a recursion whose rows are 64 bytes
 // long (n = 8 doubles), where the row reads of (Q e)_j conflict
 template <class S, int N, bool EXACT> constexpr bool cost_transposed() { return EXACT && sizeof(S) == sizeof(double) && N == 8; }
+// the exact mode's pinned sweep runs on matrix-core tiles where the clipped mode's backward sweep does (traceless real path of a
+// shape with HAS_TILE): config 3 exact 208 -> 190 ms (profiles/r04_ab_experiments.txt)
+template <class S, bool TL, bool EXACT> constexpr bool exact_tile() { return EXACT && TL && HAS_TILE && sizeof(S) == sizeof(double); }
 template <class S, bool TL = false, bool TILE = false, bool EXACT = false>
 constexpr size_t mpc_lds_layout_bytes() {
   constexpr int N = TL ? NX - 1 : NX;
   return sizeof(S) * (size_t)(ROWS * model_elems<N>() + cost_elems<N>() + (cost_transposed<S, N, EXACT>() ? 2 * N * N : 0)) +
          sizeof(cplx) * (size_t)(ROWS * SCRATCH_ELEMS) + sizeof(double) * (size_t)WLS_DOUBLES + (size_t)stash_bytes<S>() +
-         (TILE ? (size_t)TILE_LDS_BYTES : 0);
+         (TILE ? (size_t)TILE_LDS_BYTES : 0) + (exact_tile<S, TL, EXACT>() ? (size_t)(TILE_LDS_BYTES + TILE_PIN_LDS_BYTES) : 0);
 }
 
 __device__ __forceinline__ int row_bcast_int(int v) { return __shfl(v, 0, 16); }
@@ -165,6 +168,46 @@ struct RowStash {
   __device__ __forceinline__ void put_x(cplx v) const { xm[2 * threadIdx.x] = v.re; xm[2 * threadIdx.x + 1] = v.im; }
   __device__ __forceinline__ void get_x(double& v) const { v = xm[2 * threadIdx.x]; }
   __device__ __forceinline__ void get_x(cplx& v) const { v.re = xm[2 * threadIdx.x]; v.im = xm[2 * threadIdx.x + 1]; }
+};
+
+// the exact mode's pinned sweep on tiles: what a row hands to the tile layout (member = (lane >> 2) & 3 there, lane >> 4 in rows)
+template <int NS>
+struct ExactTile {
+  static constexpr bool enabled = true;
+  const double* lds_models;
+  volatile M4Q_LDS double* tgb; volatile M4Q_LDS int* tiw; volatile M4Q_LDS double* tpin;
+  GView Xg, Ug, gains;
+  const double* Q; const double* Qf; const double* R;
+  unsigned sX, sU, sG;
+  int g, jj;
+  __device__ __forceinline__ void sweep(int T, const Window& win, const PinCtx<NU>& pin, bool going) const {
+    if (jj == 0) {
+      tiw[g * TILE_IO_WORDS + 0] = going ? 1 : 0;
+      tiw[g * TILE_IO_WORDS + 1] = (int)win.xbm.off;
+      tiw[g * TILE_IO_WORDS + 2] = (int)win.ubm.off;
+      tiw[g * TILE_IO_WORDS + 3] = (int)pin.stat.off;
+#pragma unroll
+      for (int k = 0; k < NU; ++k) { tpin[g * TILE_PIN_DOUBLES + k] = pin.lo0[k]; tpin[g * TILE_PIN_DOUBLES + 3 + k] = pin.hi0[k]; }
+    }
+    wave_sync();
+    TileBackwardB<NS, NU, ORDER, true> ts;
+    const int mb = ts.L.mb;
+    const int dm = mb - g;
+    ts.mdl = lds_models + mb * model_elems<NS>();
+    ts.T = T;
+    ts.Xg = Xg; ts.Xg.off = Xg.off + (unsigned)(dm * (int)(sX * sizeof(double)));
+    ts.Ug = Ug; ts.Ug.off = Ug.off + (unsigned)(dm * (int)(sU * sizeof(double)));
+    ts.gains = gains; ts.gains.off = gains.off + (unsigned)(dm * (int)(sG * sizeof(double)));
+    ts.xbm = win.xbm; ts.xbm.off = (unsigned)tiw[mb * TILE_IO_WORDS + 1];
+    ts.ubm = win.ubm; ts.ubm.off = (unsigned)tiw[mb * TILE_IO_WORDS + 2];
+    ts.stat = pin.stat; ts.stat.off = (unsigned)tiw[mb * TILE_IO_WORDS + 3];
+    ts.sat = pin.box.sat;
+    ts.Q = Q; ts.Qf = Qf; ts.R = R;
+    ts.gb = tgb + mb * TILE_GB_DOUBLES;
+    const bool run_t = tiw[mb * TILE_IO_WORDS + 0] != 0;
+    ts.backward(run_t);
+    wave_sync();
+  }
 };
 
 // TL: the state lives in the NX - 1 traceless coordinates (S = double only; m4q_mpc.h).  NS = dimension of the recursion;
@@ -222,6 +265,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
   // TILE: hand-over block between the DPP-row state machine and the tile sweeps, and the G / h broadcast tiles
   volatile M4Q_LDS double* tgb = stash.xm + 64 * 2;
   volatile M4Q_LDS int* tiw = (volatile M4Q_LDS int*)(tgb + ROWS * TILE_GB_DOUBLES);
+  volatile M4Q_LDS double* tpin = (volatile M4Q_LDS double*)(tiw + ROWS * TILE_IO_WORDS);      // (exact_tile kernels only)
   int T0, flags;
   bool ls_diag, two_phase;
   int n_pieces;                // work items per instance: head [step_begin, 2), then [2, XCUTS[0]), ... , [.., step_end)
@@ -600,7 +644,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
           if (!finite_d(J0)) { qp.busy() = false; bad_start = true; }
         }
         if (__any(qp.busy())) ++qp_passes;
-        const bool ended = box_qp_iterate<S, NS, NU>(prov, fresh(T), x_cur, win, cost, flags, gains, pin, Xo, Uo, Xalt, Ualt, qp, j, jj, lane_ok, &pc);
+        bool ended;
+        if constexpr (exact_tile<S, TL, EXACT>()) {
+          // the pinned sweep on tiles: what a row hands to the tile layout (member = (lane >> 2) & 3 there, lane >> 4 here)
+          ExactTile<NS> xt;
+          xt.lds_models = reinterpret_cast<const double*>(lds);
+          xt.tgb = tgb; xt.tiw = tiw; xt.tpin = tpin;
+          xt.Xg = Xg; xt.Ug = Ug; xt.gains = gains;
+          xt.Q = reinterpret_cast<const double*>(cost.Q); xt.Qf = reinterpret_cast<const double*>(cost.Qf); xt.R = reinterpret_cast<const double*>(cost.R);
+          xt.sX = sX; xt.sU = sU; xt.sG = sG;
+          xt.g = g; xt.jj = jj;
+          ended = box_qp_iterate<S, NS, NU>(prov, fresh(T), x_cur, win, cost, flags, gains, pin, Xo, Uo, Xalt, Ualt, qp, j, jj, lane_ok, &pc, xt);
+        } else {
+          ended = box_qp_iterate<S, NS, NU>(prov, fresh(T), x_cur, win, cost, flags, gains, pin, Xo, Uo, Xalt, Ualt, qp, j, jj, lane_ok, &pc);
+        }
         solved = running && (ended || bad_start);
         capped = solved && !bad_start && qp.stats.end_cap > 0;
         chk = qp.Jk;

@@ -44,6 +44,7 @@ enum : int {
   QP_DU_BAND = 2,   // clip the first control to u_prev +- du as well (optimize.py:29-30)
   QP_EXACT_BOX = 4, // solve the box-constrained QP to optimality (projected Newton) instead of clipping the Riccati rollout
   QP_TARG_CONST = 256,   // internal (set by the host when every column of X_targ is the same): xbar_t does not depend on t
+  QP_NO_TILE = 512,      // internal (M4Q_OPT_NO_TILE in the exact mode, whose kernel holds both forms of the pinned sweep)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1420,12 +1421,21 @@ struct BoxQpRow {
 #endif
 constexpr int PDAS_CAP = M4Q_PDAS_CAP;
 
+// The pinned sweep of box_qp_iterate on matrix-core tiles instead of DPP rows (m4q_tile3.h: TileBackwardB<..., PINNED>), where the
+// kernel provides it: an object with `enabled` and sweep(T, win, pin, store_ok).  NoTileSweep: DPP rows.
+struct NoTileSweep {
+  static constexpr bool enabled = false;
+  template <int NU>
+  __device__ __forceinline__ void sweep(int, const Window&, const PinCtx<NU>&, bool) const {}
+};
+
 // One iteration of the exact solve for the rows of the wavefront that have one in progress (r.busy()).  Returns true for
 // the rows whose solve ended in this call: r.Jk is then the objective of the answer, r.cur_is_a() says where it is.
-template <class S, int NX, int NU, class Prov, bool TR = false>
+template <class S, int NX, int NU, class Prov, bool TR = false, class TileSweep = NoTileSweep>
 __device__ __forceinline__ bool box_qp_iterate(const Prov& prov, int T, S x0, const Window& win, const CostRef<S, TR>& cost, int flags,
                                                const GView& gains, PinCtx<NU>& pin, GView Xa, GView Ua, GView Xb, GView Ub,
-                                               BoxQpRow& r, int j, int jj, bool lane_ok, PhaseClock* pc = nullptr) {
+                                               BoxQpRow& r, int j, int jj, bool lane_ok, PhaseClock* pc = nullptr,
+                                               const TileSweep& tile = TileSweep()) {
   PhaseClock none;
   PhaseClock& clk = pc ? *pc : none;
   r.was_busy() = r.busy();
@@ -1471,7 +1481,12 @@ __device__ __forceinline__ bool box_qp_iterate(const Prov& prov, int T, S x0, co
     r.was_pdas() = r.pdas();
     if (r.going()) ++r.iters;
     // (constant target: the sweep's constant-target form, as in the clipped mode - a wave-uniform choice between two instantiations)
-    if constexpr (sizeof(S) == sizeof(double) && NX >= 8) {
+    if constexpr (TileSweep::enabled) {
+      // (constant target: the pinned sweep on matrix-core tiles, as the clipped mode's backward sweep - m4q_tile3.h)
+      // (M4Q_OPT_NO_TILE: the DPP sweep for any target, which this kernel holds anyway)
+      if ((flags & (QP_TARG_CONST | QP_NO_TILE)) == QP_TARG_CONST) tile.sweep(Tf(), win, pin, r.going());
+      else riccati_backward<S, NX, NU, Prov, true>(prov, Tf(), win, cost, flags, gains, j, r.going() && ok(), &pin);
+    } else if constexpr (sizeof(S) == sizeof(double) && NX >= 8) {
       if ((flags & QP_TARG_CONST) != 0) riccati_backward<S, NX, NU, Prov, true, true>(prov, Tf(), win, cost, flags, gains, j, r.going() && ok(), &pin);
       else riccati_backward<S, NX, NU, Prov, true>(prov, Tf(), win, cost, flags, gains, j, r.going() && ok(), &pin);
     } else {

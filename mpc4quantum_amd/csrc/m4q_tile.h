@@ -50,10 +50,15 @@ __device__ __forceinline__ double mm(double x, double y, double c) { return __bu
 
 // Hand-over between the closed-loop state machine (DPP rows: member = lane >> 4) and the tile sweep (member = (lane >> 2) & 3):
 // per member 4 words of LDS, and the 16 doubles through which G = R + B^H P B and h reach all of a member's lanes.
-constexpr int TILE_IO_WORDS = 4;        // [0] flags (1 running) | [1] xbm byte offset | [2] ubm byte offset | [3] spare
+constexpr int TILE_IO_WORDS = 4;        // [0] flags (1 running) | [1] xbm byte offset | [2] ubm byte offset | [3] exact mode: working-set byte offset
 constexpr int TILE_GB_DOUBLES = 18;     // the G / h tile of one member: 16 doubles at a pitch of 18 - every lane of a member reads the
                                         // same entry, and at pitch 16 (128 bytes) members 0 / 2 and 1 / 3 read the same banks: 46 % of the
                                         // tile kernel's LDS-active cycles were bank conflicts (profiles/r04_tile_chain.txt)
 constexpr int TILE_LDS_BYTES = 4 * (TILE_IO_WORDS * 4 + TILE_GB_DOUBLES * 8);
+// exact mode (pinned sweep on tiles): per member also the working-set view's byte offset (word [3]) and the first control's band
+// (a member's block sits at a constant distance behind its gains block: one address register serves both)
+constexpr int TILE_PIN_DOUBLES = TILE_GB_DOUBLES;     // [0, 3) lo0 | [3, 6) hi0 | spare
+constexpr int TILE_PIN_LDS_BYTES = 4 * TILE_PIN_DOUBLES * 8;
+constexpr int TILE_PIN_OFFSET = 4 * TILE_GB_DOUBLES + 4 * TILE_IO_WORDS / 2;      // in doubles, from a member's gb block
 
 }  // namespace m4q

@@ -29,7 +29,15 @@ __device__ __forceinline__ double quad_bcast(double x) {
   return __hiloint2double(hi, lo);
 }
 
-template <int NS, int NU, int ORDER>
+// a wave-uniform double into scalar registers
+__device__ __forceinline__ double to_sgpr(double x) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
+
+// PINNED: the sweep of the exact box-QP iteration (riccati_backward<PINNED> of m4q_mpc.h, same algebra): controls of the working
+// set `stat` ([T][NU]: 0 free, +1 / -1 pinned at the upper / lower bound) are constants of their stage; the stored row of a pinned
+// control is the affine form of its multiplier.
+template <int NS, int NU, int ORDER, bool PINNED = false>
 struct TileBackwardB {
   static constexpr int NT = (NS + 3) / 4;
   static constexpr int NP = PowTab<NU, ORDER>::NP;
@@ -41,6 +49,17 @@ struct TileBackwardB {
   const double* mdl;                                    // LDS [1+NP][NS][PITCH], this lane's member
   GView Xg, Ug, gains, xbm, ubm;                        // positioned on this lane's member
   volatile __attribute__((address_space(3))) double* gb;       // LDS, 16 doubles, this lane's member
+  // PINNED: the working set of this lane's member, the box, and the first control's band (u_prev +- du: [0, NU) lo0, [3, 3 + NU) hi0
+  // at gb + TILE_PIN_OFFSET - read at t = 0 only).
+  GView stat;
+  double sat = 0.0;
+  // Registers.  The kernels around this sweep keep up to a hundred registers of their own across it, so what the sweep can hold in
+  // scalar registers (R, the box, the lane masks of the column / row selectors) or re-read from LDS at every index (Q's tiles at
+  // n = 4k, the band) it does, and the lane's addresses are made values of THIS sweep (see backward()).  With all of that in
+  // vector registers the first pinned sweep had the compiler reload spilled addresses inside the horizon loop, where every
+  // reload's s_waitcnt vmcnt(0) also waits for the operand loads issued a block ahead: config 3 exact 224 ms, against 208 on DPP
+  // rows and 190 in this form; the clipped kernel lost its last 44 spilled registers, 32.07 -> 31.26 ms
+  // (profiles/r04_ab_experiments.txt; the model's tiles from LDS as well: 32.0 and 194 ms - they stay in registers).
 
   __device__ __forceinline__ double mdl_nat(int p, int I, int J) const {
     const int i = 4 * I + L.r, k = 4 * J + L.q;
@@ -61,6 +80,7 @@ struct TileBackwardB {
   struct Blk {                // operands of the four indices tb, tb - 1, tb - 2, tb - 3: this lane holds time tb - q
     double xt[NT];
     double ug[NU], ub[NU];
+    double st[PINNED ? NU : 1];
   };
   __device__ __forceinline__ Blk load_blk(int tb) const {
     Blk b;
@@ -74,16 +94,32 @@ struct TileBackwardB {
     }
     ldn<NU>(Ug, (unsigned)tq * NU, b.ug);
     ldn<NU>(ubm, (unsigned)tq * NU, b.ub);
+    if constexpr (PINNED) ldn<NU>(stat, (unsigned)tq * NU, b.st);
     return b;
   }
 
-  __device__ __forceinline__ void backward(bool store_ok) const {
-    double M[1 + NP][NT][NT], NpT[NP][NT][NT], P[NT][NT], pv[NT], xb[NT], tt[1 + NP][NT], Qt[NT][NT];
+  __device__ __forceinline__ void backward(bool store_ok) {
+    {
+      // the lane's addresses as values of THIS sweep: as the kernel-long values they are, the register allocator spills them and
+      // reloads them at every use inside the horizon loop
+      asm volatile("" : "+v"(Xg.off), "+v"(Ug.off), "+v"(gains.off), "+v"(ubm.off));
+      if constexpr (PINNED) asm volatile("" : "+v"(stat.off));
+      asm volatile("" : "+v"(L.q), "+v"(L.r));
+      L.q &= 3; L.r &= 3;
+      const __attribute__((address_space(3))) double* ml = (const __attribute__((address_space(3))) double*)mdl;
+      const __attribute__((address_space(3))) double* ql = (const __attribute__((address_space(3))) double*)Q;
+      asm volatile("" : "+v"(gb), "+v"(ml), "+v"(ql));
+      mdl = (const double*)ml;
+      Q = (const double*)ql;
+    }
+    constexpr bool QLDS = NS % 4 == 0;           // Q's tiles re-read from LDS at every index (no masking at n = 4k)
+    double M[1 + NP][NT][NT], NpT[NP][NT][NT], P[NT][NT], pv[NT], xb[NT], tt[1 + NP][NT], Qt[QLDS ? 1 : NT][QLDS ? 1 : NT];
+    const double* Qlane = Q + L.r * NS + L.q;
 #pragma unroll
     for (int I = 0; I < NT; ++I)
 #pragma unroll
       for (int J = 0; J < NT; ++J) {
-        Qt[I][J] = sym_nat(Q, I, J);
+        if constexpr (!QLDS) Qt[I][J] = sym_nat(Q, I, J);
         P[I][J] = sym_nat(Qf, I, J);
 #pragma unroll
         for (int p = 0; p <= NP; ++p) M[p][I][J] = mdl_nat(p, I, J);
@@ -108,19 +144,21 @@ struct TileBackwardB {
       }
 #pragma unroll
     for (int I = 0; I < NT; ++I) tt[0][I] -= xb[I];                  // A xbar - xbar_{t+1} (constant target)
-    double mq[NU + 1], mr[NU];
+    bool isq[NU + 1], isr[NU];                                        // column / row selectors: lane masks (scalar registers)
 #pragma unroll
-    for (int s = 0; s <= NU; ++s) mq[s] = L.q == s ? 1.0 : 0.0;
+    for (int s = 0; s <= NU; ++s) isq[s] = L.q == s;
 #pragma unroll
-    for (int s = 0; s < NU; ++s) mr[s] = L.r == s ? 1.0 : 0.0;
+    for (int s = 0; s < NU; ++s) isr[s] = L.r == s;
     double Rm[NU][NU];
 #pragma unroll
     for (int s = 0; s < NU; ++s)
 #pragma unroll
-      for (int l = 0; l < NU; ++l) Rm[s][l] = R[s * NU + l];
+      for (int l = 0; l < NU; ++l) Rm[s][l] = to_sgpr(R[s * NU + l]);
+    const double satu = to_sgpr(sat);
 
     // one horizon index; ug / ub: its controls and control targets, b: rowrep(N_s x_g), all replicated over the member's lanes
-    auto step = [&](int t, const double (&ug)[NU], const double (&ub)[NU], const double (&b)[NU][NT]) __attribute__((always_inline)) {
+    auto step = [&](int t, const double (&ug)[NU], const double (&ub)[NU], const double (&b)[NU][NT],
+                    const double (&stv)[NU]) __attribute__((always_inline)) {
       double At[NT][NT], c[NT], W[NT], Y[NT], H[NT];
 #pragma unroll
       for (int I = 0; I < NT; ++I)
@@ -139,14 +177,14 @@ struct TileBackwardB {
 #pragma unroll
         for (int s = 0; s < NU; ++s) a = fma(b[s][K], ub[s] - ug[s], a);        // + B ubar + Delta, Delta = -B u_g
         c[K] = a;
-        double w = mq[NU] * a;
+        double w = isq[NU] ? a : 0.0;                                           // W = [B | c | 0]
 #pragma unroll
-        for (int s = 0; s < NU; ++s) w = fma(mq[s], b[s][K], w);
+        for (int s = 0; s < NU; ++s) w = isq[s] ? b[s][K] : w;
         W[K] = w;
       }
 #pragma unroll
       for (int I = 0; I < NT; ++I) {
-        double acc = mq[NU] * pv[I];
+        double acc = isq[NU] ? pv[I] : 0.0;
 #pragma unroll
         for (int K = 0; K < NT; ++K) acc = mm(P[K][I], W[K], acc);              // Y = P W + [0 | p | 0]
         Y[I] = acc;
@@ -172,25 +210,75 @@ struct TileBackwardB {
         h[s] = gb[s * 4 + NU];
       }
       wave_sync();
+      bool fix[NU];
+      double dufix[NU], hraw[NU], Gf[NU][NU];
+#pragma unroll
+      for (int s = 0; s < NU; ++s) { fix[s] = false; dufix[s] = 0.0; hraw[s] = 0.0; }
+      if constexpr (PINNED) {
+        // controls pinned at a bound are constants of the stage: K row = [0 | du_fix]; the free ones respond to them:
+        //   G_ff du_f = -(H_f dx + h_f + G_fp du_p)                                          (riccati_backward<PINNED>, m4q_mpc.h)
+#pragma unroll
+        for (int s = 0; s < NU; ++s) {
+          double lo = -satu, hi = satu;
+          if (t == 0) { lo = fmax(lo, gb[TILE_PIN_OFFSET + s]); hi = fmin(hi, gb[TILE_PIN_OFFSET + 3 + s]); }
+          fix[s] = stv[s] != 0.0;
+          dufix[s] = fix[s] ? (stv[s] > 0.0 ? hi : lo) - ub[s] : 0.0;
+#pragma unroll
+          for (int l = 0; l < NU; ++l) Gf[s][l] = s <= l ? gm[s][l].re : gm[l][s].re;
+        }
+#pragma unroll
+        for (int s = 0; s < NU; ++s) {
+#pragma unroll
+          for (int l = 0; l < NU; ++l) h[s] = fma(Gf[s][l], dufix[l], h[s]);
+          hraw[s] = h[s];
+        }
+#pragma unroll
+        for (int s = 0; s < NU; ++s) {
+#pragma unroll
+          for (int l = s; l < NU; ++l)
+            if (fix[s] || fix[l]) gm[s][l] = mk(s == l ? 1.0 : 0.0, 0.0);
+          if (fix[s]) h[s] = 0.0;
+        }
+      }
       herm_inverse<NU>(gm, ginv);
-      double cf[NU], kk[NU];
+      // cf[s]: the coefficients of H's rows in K_s (a tile: -G^-1[s][r] in every q; rows of pinned controls do not enter);
+      // cst[s]: the same for the row that is STORED - K_s for a free control, for a pinned one the affine form of its multiplier,
+      //   mu_s(dx) = [H_s + sum_{l free} G_sl K_l] dx + h_s + sum_l G_sl du_l
+      double cf[NU], kk[NU], cst[NU], kst[NU];
 #pragma unroll
       for (int s = 0; s < NU; ++s) {
         double cs = 0.0, ks = 0.0;
 #pragma unroll
         for (int l = 0; l < NU; ++l) {
-          cs = fma(-ginv[s][l].re, mr[l], cs);
+          cs = (isr[l] && !fix[l]) ? -ginv[s][l].re : cs;
           ks = fma(-ginv[s][l].re, h[l], ks);
         }
         cf[s] = cs;
-        kk[s] = ks;
+        kk[s] = fix[s] ? dufix[s] : ks;
       }
-      double Kc[NU][NT], Kr[NU][NT];
+#pragma unroll
+      for (int s = 0; s < NU; ++s) {
+        cst[s] = cf[s];
+        kst[s] = kk[s];
+        if constexpr (PINNED) {
+          double m = 0.0, c0 = hraw[s];
+#pragma unroll
+          for (int l = 0; l < NU; ++l) {
+            m = fma(fix[l] ? 0.0 : Gf[s][l], cf[l], m);
+            c0 = fma(fix[l] ? 0.0 : Gf[s][l], kk[l], c0);           // (pinned l: G_sl du_fix_l is already inside hraw)
+          }
+          m = isr[s] ? m + 1.0 : m;             // (+ e_s: a 0/1 tile would be one more lane constant to keep or spill)
+          cst[s] = fix[s] ? m : cf[s];
+          kst[s] = fix[s] ? c0 : kk[s];
+        }
+      }
+      double Kc[NU][NT], Kr[NU][NT], Ks[NU][NT];
 #pragma unroll
       for (int s = 0; s < NU; ++s)
 #pragma unroll
         for (int J = 0; J < NT; ++J) {
-          Kc[s][J] = mm(cf[s], H[J], 0.0);                                      // K_s[4J + q] in every r
+          Ks[s][J] = mm(cst[s], H[J], 0.0);                                     // the stored row: [4J + q] in every r
+          Kc[s][J] = PINNED ? (fix[s] ? 0.0 : Ks[s][J]) : Ks[s][J];             // K_s[4J + q] in every r (a pinned control: 0)
           Kr[s][J] = mm(H[J], cf[s], 0.0);                                      // K_s[4J + r] in every q
         }
       if (store_ok) {
@@ -201,10 +289,10 @@ struct TileBackwardB {
         for (int J = 0; J < NT; ++J) {
           double kc[NU];
 #pragma unroll
-          for (int s = 0; s < NU; ++s) kc[s] = Kc[s][J];
+          for (int s = 0; s < NU; ++s) kc[s] = Ks[s][J];
           if (NS % 4 == 0 || 4 * J + L.q < NS) stn<NU>(gains, gt + (4 * J + L.q) * NU, kc);
         }
-        stn<NU>(gains, gt + NS * NU, kk);
+        stn<NU>(gains, gt + NS * NU, kst);
       }
       double S[NT][NT], sv[NT], PS[NT][NT], w[NT];
 #pragma unroll
@@ -260,7 +348,9 @@ struct TileBackwardB {
         pv[I] = pn;
 #pragma unroll
         for (int J = 0; J < NT; ++J) {
-          double e = Qt[I][J];
+          double e;
+          if constexpr (QLDS) e = Qlane[4 * I * NS + 4 * J];
+          else e = Qt[I][J];
 #pragma unroll
           for (int s = 0; s < NU; ++s) e = fma(Kr[s][I], RK[s][J], e);
 #pragma unroll
@@ -284,15 +374,16 @@ struct TileBackwardB {
       static_for<0, 4>([&](auto jj) {
         constexpr int j = decltype(jj)::value;
         if (j < cnt) {
-          double ug[NU], ub[NU], b[NU][NT];
+          double ug[NU], ub[NU], b[NU][NT], stv[NU];
 #pragma unroll
           for (int s = 0; s < NU; ++s) {
             ug[s] = quad_bcast<j>(cur.ug[s]);
             ub[s] = quad_bcast<j>(cur.ub[s]);
+            stv[s] = PINNED ? quad_bcast<j>(cur.st[s]) : 0.0;
 #pragma unroll
             for (int I = 0; I < NT; ++I) b[s][I] = quad_bcast<j>(BT[s][I]);
           }
-          step(tb - j, ug, ub, b);
+          step(tb - j, ug, ub, b, stv);
         }
       });
     };

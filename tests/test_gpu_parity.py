@@ -743,12 +743,15 @@ def _oracle_exact_step_sensitivity(p, models, b, k, xs, us, guess):
     return [max(np.abs(o[i] - outs[0][i]).max() for o in outs[1:]) for i in range(2)]
 
 
-@pytest.mark.parametrize("cfg,order,batch,path", [(2, 1, 3, "real"), (3, 1, 2, "real"), (3, 1, 2, "complex"), (4, 1, 2, "real")])
+@pytest.mark.parametrize("cfg,order,batch,path", [(2, 1, 3, "real"), (3, 1, 2, "real"), (3, 1, 2, "dpp"), (3, 1, 2, "complex"),
+                                                  (4, 1, 2, "real")])
 def test_closed_loop_exact_stepwise_teacher_forced(cfg, order, batch, path):
     """M4Q_QP_EXACT_BOX at the BASELINE sizes (config 2: T = 20, config 3 order 1: T = 40, config 4: T = 40), every MPC step of
     the run started from the ORACLE's state (exact mode: BVLS on the condensed box QP, the statement of optimize.py:27-54):
     the same number of SQP iterations, us[k] within 1e-9 of the bound and xs[k+1] within 1e-9 - plus, where a step is
-    ill-conditioned, ten times what the oracle itself moves under a 1e-15 perturbation of the step's starting guess."""
+    ill-conditioned, ten times what the oracle itself moves under a 1e-15 perturbation of the step's starting guess.
+    "real" at d = 2, 3 runs the pinned sweep on matrix-core tiles (m4q_tile3.h, the default), "dpp" the same kernel's DPP sweep
+    (M4Q_OPT_NO_TILE)."""
     p = configs.build(cfg, batch=max(batch, 4) if cfg == 3 else batch, order=order)
     idx = np.arange(batch)
     trace = []
@@ -760,11 +763,11 @@ def test_closed_loop_exact_stepwise_teacher_forced(cfg, order, batch, path):
     q = dict(p)
     q["models"] = models
     ns = p["n_steps"]
-    sess = _session(q, batch, force_complex=(path == "complex"), exact_qp=True)
+    sess = _session(q, batch, force_complex=(path == "complex"), exact_qp=True, **({"tile": False} if path == "dpp" else {}))
     try:
         sess.load_problem(models, p["x0"][idx], p["X_targ"], p["U_targ"], p["Q"], p["R"], p["Qf"], p["plant_op0"],
                           p["plant_ops"])
-        assert sess.path() == path
+        assert sess.path() == ("real" if path == "dpp" else path)
         xs_t, us_t = np.swapaxes(xs, 1, 2), np.swapaxes(us, 1, 2)
         admitted = []
         for k in range(ns):
@@ -1219,7 +1222,8 @@ def test_properties_at_full_baseline_size(cfg, batch):
     assert np.abs(us).max() > 0.5 * p["sat"]                       # (and the ensemble is really being driven)
 
 
-@pytest.mark.parametrize("kw", [{}, {"tile": False}, {"exact_qp": True}, {"force_complex": True}, {"traceless": False}])
+@pytest.mark.parametrize("kw", [{}, {"tile": False}, {"exact_qp": True}, {"exact_qp": True, "tile": False}, {"force_complex": True},
+                                {"traceless": False}])
 def test_repeated_launches_are_bit_identical(kw):
     """Rows pull their work from a device-wide queue, heads and tails of a run may land on different workgroups, and in the
     exact mode a solve spans a varying number of passes: none of that may reach the numbers.  Four launches of the same
@@ -1254,7 +1258,7 @@ def test_repeated_launches_are_bit_identical(kw):
         h.update(np.ascontiguousarray(first[key]).tobytes())
     name = "config3_B4096_" + ("exact" if kw.get("exact_qp") else "clip") + (
         "_complex" if kw.get("force_complex") else "_real9" if kw.get("traceless") is False else
-        "_real" if (kw.get("tile") is False or kw.get("exact_qp")) else "_tile")      # ({}: the default - backward sweep on tiles)
+        "_real" if kw.get("tile") is False else "_tile")      # ({}: the default - backward / pinned sweep on tiles)
     store = os.environ.get("M4Q_STORE_CHECKSUMS")
     if store:
         have = json.load(open(store)) if os.path.exists(store) else {}

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where the spills are: for every loop of a compiled kernel whose body holds > 100 DPP FMAs (the horizon loops), count the
+"""Where the spills are: for every loop of a compiled kernel whose body holds > 100 DPP FMAs or >= 40 fp64 MFMAs (the horizon loops), count the
 scratch (spill) instructions, LDS reads, waits and register moves inside it.
 
     python3 tools/hot_loops.py 9_2_1 'mpc_kernelIdLi1ELb0'        # shape, substring of the mangled kernel name
@@ -51,11 +51,12 @@ def main():
                 continue
             body = L[amap[t]:i + 1]
             dpp = sum("v_fmac_f64_dpp" in x for x in body)
-            if dpp <= int(sys.argv[3] if len(sys.argv) > 3 else 100) or len(body) > 2500:
+            mfma = sum("v_mfma_f64" in x for x in body)
+            if (dpp <= int(sys.argv[3] if len(sys.argv) > 3 else 100) and mfma < 40) or len(body) > 4000:
                 continue
             cnt = lambda p: sum(re.match(r"\s+" + p, x) is not None for x in body)   # noqa: E731
-            print("   loop of %4d instructions: %4d v_fmac_f64_dpp, %3d other fp64 FMA, scratch loads %d stores %d, LDS reads %d, "
-                  "s_waitcnt %d, s_nop %d, v_mov/accvgpr %d" % (len(body), dpp, cnt("v_fma_f64|v_fmac_f64_e"), cnt("scratch_load"),
+            print("   loop of %4d instructions: %3d fp64 MFMA, %4d v_fmac_f64_dpp, %3d other fp64 FMA, scratch loads %d stores %d, LDS reads %d, "
+                  "s_waitcnt %d, s_nop %d, v_mov/accvgpr %d" % (len(body), mfma, dpp, cnt("v_fma_f64|v_fmac_f64_e"), cnt("scratch_load"),
                                                                 cnt("scratch_store"), cnt("ds_read"), cnt("s_waitcnt"), cnt("s_nop"),
                                                                 cnt("v_mov|v_accvgpr")))
 
