@@ -421,14 +421,16 @@ def main():
                          "frac": flops_exec / avg_launch_s / 1e12 / PEAK_F64_TFLOPS, "traffic": traffic,
                          "kernel": "mpc_kernel<%s, PLANT_HAMILTONIAN, %s%s>" % (
                              "double" if path == "real" else "cplx", "true" if args.exact_qp else "false",
-                             ", TL, TILE" if detail == "traceless-tile" else ", TL" if detail == "traceless" else ""),
+                             ", TL, TILE" if detail == "traceless-tile" and not args.exact_qp else
+                             ", TL" if detail in ("traceless", "traceless-tile") else ""),
                          "launches": launches, "avg_launch_ms": 1e3 * avg_launch_s,
                          "flop_per_horizon_step": executed_flop_per_hstep(n, m, P, detail, targ_const), "horizon_steps_per_launch": hsteps,
                          "note": "compute-bound kernel: intensity >> the fp64 machine balance, so the binding roof is the fp64 pipe "
                                  "(v_fma_f64 with DPP row broadcasts%s; fp64 MFMA and fp64 VALU share one pipe and one peak).  achieved = "
                                  "flops of the recursion the selected path performs (real path: a quarter of SURVEY 8d's "
                                  "complex-recursion count; products padded to 4 x 4 tiles are not counted twice) / HIP-event launch "
-                                 "time" % (", and - the backward sweep - v_mfma_f64_4x4x4_4b_f64 tiles" if detail == "traceless-tile" else ""),
+                                 "time" % (", and - the %s sweep - v_mfma_f64_4x4x4_4b_f64 tiles" % ("pinned" if args.exact_qp else "backward")
+                                           if detail == "traceless-tile" else ""),
                          "algorithmic_equivalent": {"achieved": flops_alg / avg_launch_s / 1e12, "unit": "TFLOP/s",
                                                     "note": "SURVEY 8d complex-recursion flops / time: a speed-up-adjusted throughput, "
                                                             "NOT a fraction of any roof (exceeds the peak on the real path at d=4)"},

@@ -307,10 +307,11 @@ struct m4q_session {
   }
   // 0 complex, 1 real (Hermitian basis), 2 real traceless.  diag: the line-search blocks of the costs are diagonal (known after
   // the first run; m4q_session_path answers as if they were before that)
-  //                         3 traceless with the sweeps of the clipped solve on matrix-core tiles (constant targets only)
+  //                         3 traceless with the backward sweep of the clipped solve / the pinned sweep of the exact solve on
+  //                           matrix-core tiles (constant targets only)
   int path(bool diag) const {
     if (!use_traceless(diag)) return use_real(diag) ? 1 : 0;
-    return (!no_tile && targ_const && !(prob.qp_flags & M4Q_QP_EXACT_BOX)) ? 3 : 2;
+    return (!no_tile && targ_const) ? 3 : 2;
   }
   int path() const { return path(ls_diag); }
   std::vector<double> hQ, hQf, hR;

@@ -1199,8 +1199,8 @@ __global__ __launch_bounds__(64) void discretize_kernel(DiscArgs a) {
 // ---------------------------------------------------------------------------------------------
 static size_t mpc_lds_bytes(int path, int exact) {
   if constexpr (SQUARE) {
-    if constexpr (HAS_TILE) { if (path == 3) return mpc_lds_layout_bytes<double, true, true>(); }
-    if (path == 2) return exact ? mpc_lds_layout_bytes<double, true, false, true>() : mpc_lds_layout_bytes<double, true, false>();
+    if constexpr (HAS_TILE) { if (path == 3 && !exact) return mpc_lds_layout_bytes<double, true, true>(); }
+    if (path >= 2) return exact ? mpc_lds_layout_bytes<double, true, false, true>() : mpc_lds_layout_bytes<double, true, false>();
   }
   if (path) return exact ? mpc_lds_layout_bytes<double, false, false, true>() : mpc_lds_layout_bytes<double>();
   return mpc_lds_layout_bytes<cplx>();
@@ -1261,8 +1261,9 @@ static int pick_plant(const Op& op, int plant_kind) {
   }
 }
 
-// path: 0 complex, 1 real (Hermitian basis, NX coordinates), 2 real traceless (NX - 1 coordinates), 3 traceless with the two
-// sweeps on matrix-core tiles (clipped solve only)
+// path: 0 complex, 1 real (Hermitian basis, NX coordinates), 2 real traceless (NX - 1 coordinates), 3 traceless with the backward
+// sweep on matrix-core tiles (clipped solve: its own kernel; exact solve: the pinned sweep inside the one exact kernel, chosen by
+// QP_TARG_CONST and QP_NO_TILE in the flags)
 template <class Op>
 static int pick_kernel(const Op& op, int plant_kind, int path, int exact, int unsupported) {
   if constexpr (!SQUARE) {

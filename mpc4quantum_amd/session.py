@@ -129,7 +129,8 @@ class EnsembleSession:
 
     def path_detail(self):
         """'complex', 'real' (d*d Hermitian coordinates), 'traceless' (the d*d - 1 traceless Hermitian coordinates) or
-        'traceless-tile' (the same with the backward sweep of the clipped solve on fp64 matrix-core tiles)."""
+        'traceless-tile' (the same with the backward sweep of the clipped solve / the pinned sweep of the exact solve on fp64
+        matrix-core tiles)."""
         return ("complex", "real", "traceless", "traceless-tile")[_lib.check(self._L.m4q_session_path(self._h))]
 
     def info(self):

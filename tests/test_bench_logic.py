@@ -50,9 +50,9 @@ def test_counter_records_are_refused_when_stale(tmp_path, monkeypatch):
 def test_committed_counter_records_cover_every_baseline_config():
     recs = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc.json")))
     # (d = 2, 3 run their backward sweep on matrix-core tiles: key suffix _tile, MFMA instructions counted; d = 4, the complex path,
-    #  the exact mode and the DPP sweeps kept for comparison execute none)
+    #  and the DPP sweeps kept for comparison execute none; the exact mode at d = 3 runs its pinned sweep on tiles)
     for key, tile in (("config2_B8192_real_clip_tile", True), ("config3_B65536_real_clip_tile", True), ("config3_B65536_real_clip", False),
-                      ("config3_B65536_complex_clip", False), ("config3_B65536_real_exact", False), ("config4_B65536_real_clip", False),
+                      ("config3_B65536_complex_clip", False), ("config3_B65536_real_exact_tile", True), ("config4_B65536_real_clip", False),
                       ("config5_B131072_real_clip_tile", True)):
         r = recs[key]
         assert r["traced_avg_launch_ms"] > 0 and r["counters"]["SQ_INSTS_VALU_FMA_F64"] > 0

@@ -1529,8 +1529,8 @@ def test_arithmetic_path_selection():
     assert detail(traceless=False) == "real"
     assert detail(qp_flags=_lib.QP_REF_LQR) == "real"
     assert detail(force_complex=True) == "complex"
-    assert detail(exact_qp=True, tile=True) == "traceless"            # the tile sweep serves the clipped solve only
-    assert detail(exact_qp=True) == "traceless"
+    assert detail(exact_qp=True) == "traceless-tile"                  # ... and the exact solve's pinned sweep
+    assert detail(exact_qp=True, tile=False) == "traceless"
 
     def ramped_target(q):                                             # a target that moves over the window: DPP sweeps
         q["X_targ"] = q["X_targ"] * np.linspace(1.0, 1.0 - 1e-3, q["X_targ"].shape[1])[None, :]
