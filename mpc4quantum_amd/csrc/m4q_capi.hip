@@ -100,7 +100,10 @@ const m4q::ShapeOps* gen_shape(int nx, int nu, int order, std::string& why) {
       }
     }
     handle = path.empty() ? nullptr : dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
-    if (!handle) load_error = "the generator-plant kernels are in libm4q_hip_gen.so, which did not load (" + path + "): " + (dlerror() ? dlerror() : "?");
+    if (!handle) {
+      const char* err = path.empty() ? nullptr : dlerror();          // (dlerror() clears itself: ask once)
+      load_error = "the generator-plant kernels are in libm4q_hip_gen.so, which did not load (" + path + "): " + (err ? err : "?");
+    }
   }
   if (!handle) { why = load_error; return nullptr; }
   char name[64];
