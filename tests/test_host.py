@@ -270,6 +270,23 @@ def test_fails_loudly_without_a_gpu():
         m4q.EnsembleSession(4, 4, 1, 1, 5, 3, 1.0, None)
 
 
+@pytest.mark.gpu
+def test_missing_generator_library_is_an_error_not_a_crash():
+    """A generator-plant session needs libm4q_hip_gen.so (loaded on first use, before any device call): when it does not load, the
+    session is refused with the loader's reason.  (Round 4: the message was built from a second dlerror() call, which returns NULL.)"""
+    import subprocess
+    import sys
+    code = ("import mpc4quantum_amd as m4q\nfrom mpc4quantum_amd import _lib\n"
+            "try:\n    m4q.EnsembleSession(4, 9, 2, 1, 5, 3, 1.0, 0.5, plant_kind=_lib.PLANT_GENERATOR)\n"
+            "except _lib.M4qError as e:\n    print('refused:', e)\n")
+    env = dict(os.environ, M4Q_GEN_LIB="/nonexistent/libm4q_hip_gen.so")
+    res = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=120)
+    assert res.returncode == 0, res.stderr.decode()[-400:]
+    out = res.stdout.decode()
+    assert "refused:" in out and "libm4q_hip_gen.so" in out and "/nonexistent" in out
+
+
 def test_streaming_dmdc_refits_vs_reference_golden(golden):
     """DiscrepDMDc / OnlineDMDc (model.py:109-313), the models mpc(..., streaming=True) refits through fit_iteration:
     batch fits and the model after each of eight streaming updates against the reference's own classes."""
