@@ -577,7 +577,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
           M4Q_PHASE_MARK(1)
         }
         wave_sync();
-        // the rollout on DPP rows (a rollout on tiles was built in round 3 and lost: m4q_tile.h)
+        // the rollout on DPP rows (on tiles it was built twice: round 3's per-index form took 2.3 times as long, round 4's time-batched
+        // form - tools/tile_rollout_r04.h - the same SIMD time at d = 3 and 14 % more of the launch at d = 2)
         // (idle lanes sit it out as in the DPP kernels: MASK_IDLE itself is off for TILE because the tile sweep needs all 64 lanes)
         constexpr bool MASK_FWD = M4Q_MASK_IDLE && NS < 16;
         if (!MASK_FWD || lane_ok)         // (the tile path runs with a constant target only)

@@ -622,6 +622,30 @@ def test_closed_loop_exact_qp_vs_oracle(cfg, order, batch, horizon, path):
     assert clip["qp_stats"] == (0, 0, 0, 0, 0, 0)
 
 
+@pytest.mark.parametrize("exact", [False, True])
+@pytest.mark.parametrize("cfg,horizon", [(3, 5), (3, 6), (3, 7), (3, 13), (2, 3), (2, 9), (1, 7)])
+def test_tile_sweeps_at_horizons_that_are_not_multiples_of_four(cfg, horizon, exact):
+    """The tile sweeps work on blocks of four horizon indices (m4q_tile3.h) and take the (T - 1) % 4 + 1 top indices first: every
+    residue of T, shorter than one block as well, on the clipped solve's backward sweep and on the exact solve's pinned sweep,
+    against the oracle's loop (first MPC step to 1e-10 / 1e-9, the short free run to the usual bounds)."""
+    p = configs.build(cfg, batch=3, order=1, horizon=horizon, n_steps=4)
+    idx = np.arange(3)
+    res = _gpu_batch(p, idx, exact_qp=exact)
+    assert res["path"] == "real" and res["path_detail"] == "traceless-tile"
+    xs, us, codes, solves = _oracle_batch(p, idx, **({"qp_mode": "exact"} if exact else {}))
+    assert np.array_equal(res["exit_codes"], codes) and np.array_equal(res["qp_solves"], solves)
+    tol = 1e-9 if exact else 1e-10
+    assert rel(res["us"][:, :, 0], us[:, :, 0]) <= tol
+    assert rel(res["xs"][:, :, 1], xs[:, :, 1]) <= tol
+    eu, ex = _envelope(p, idx, xs, us, **({"qp_mode": "exact"} if exact else {}))
+    assert np.all(np.abs(res["us"] - us).max(axis=(0, 1)) <= 1e-9 + 100 * eu)
+    assert np.all(np.abs(res["xs"] - xs).max(axis=(0, 1))[1:] <= 1e-9 + 100 * ex[1:])
+    # and the DPP sweeps of the same session agree with the tile sweeps
+    dpp = _gpu_batch(p, idx, exact_qp=exact, tile=False)
+    assert dpp["path_detail"] == "traceless"
+    assert np.abs(dpp["us"] - res["us"]).max() <= 1e-8 * p["sat"] + 100 * eu.max()
+
+
 def test_exact_qp_iteration_counts_config3():
     """What the exact mode costs on BASELINE config 3 (T = 40, 20 steps): with the primal-dual phase for the hard solves (the first
     warm steps) a solve takes 2.8 pinned sweeps on average and almost no ratio steps (round 2: 3.4 sweeps and 1.0 ratio step), and
