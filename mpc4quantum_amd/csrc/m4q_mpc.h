@@ -986,6 +986,7 @@ __device__ __forceinline__ void adjoint_pass(const Prov& prov, int T, const Wind
   auto step = [&](int t, const Ops& cur) __attribute__((always_inline)) {
     S Ac[NX], Brow[NU];
     if constexpr (AHOIST) {
+      // (the column form held in registers as well - 24 LDS reads per index less - measured: 183-186 ms either way)
       prov.col_batch(cur.lin, Ac);
 #pragma unroll
       for (int k = 0; k < NU; ++k) Brow[k] = dot_lane_index<false, false, NX>(cur.lin.xg, mregs.row[1 + k]);   // (order 1: monomial p is u_p)
@@ -1242,11 +1243,18 @@ __device__ __forceinline__ double rollout_policy(const Prov& prov, int T, S x0, 
     for (int k = 0; k < NU; ++k) o.kre[k] = real_of(kk[k]);
     return o;
   };
+  // (the row form of the model in registers over the rollout, as rollout_forward: n <= 9 real paths; exact mode 190 -> 184 ms with
+  //  this in the policy and open rollouts and their replicated u stores unmasked: profiles/r04_ab_experiments.txt)
+  constexpr bool HOIST = std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && sizeof(S) == sizeof(double) &&
+                         batch_fits<NX, NU, Prov::ORDER_>();
+  ModelRegs<S, NX, NU, Prov::ORDER_> mregs;
+  if constexpr (HOIST) mregs.load_rows(prov.mdl, j);
   auto step = [&](int t, const Ops& cur, Ops& nxt) __attribute__((always_inline)) {
     M4Q_NO_HOIST();
     nxt = load(t + 1 < T ? t + 1 : t);
     S ax, Brow[NU], dlt;
-    prov.rows(cur.lin, x, ax, Brow, dlt);
+    if constexpr (HOIST) prov.rows(mregs, cur.lin, x, ax, Brow, dlt);
+    else prov.rows(cur.lin, x, ax, Brow, dlt);
     const S dx = csub(x, cur.xb);
     cx += dot_re(dx, qrow_times<NX>(cost, t, T, dx, j));
     const S* Rt = cost.r(t);
@@ -1291,7 +1299,7 @@ __device__ __forceinline__ double rollout_policy(const Prov& prov, int T, S x0, 
     x = xn;
     if (store_ok) {
       Xc.st<S>((t + 1) * NX + j, x);
-      if (j == 0) stn<NU>(Uc, t * NU, un);
+      if (M4Q_STORE_ALL(NX) || j == 0) stn<NU>(Uc, t * NU, un);      // (replicated over the row: same bytes from every lane)
     }
   };
   Ops opsA = load(0), opsB;
@@ -1328,11 +1336,16 @@ __device__ __forceinline__ double rollout_open(const Prov& prov, int T, S x0, co
     ldn<NU>(U, t * NU, o.uin);
     return o;
   };
+  constexpr bool HOIST = std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && sizeof(S) == sizeof(double) &&
+                         batch_fits<NX, NU, Prov::ORDER_>();
+  ModelRegs<S, NX, NU, Prov::ORDER_> mregs;
+  if constexpr (HOIST) mregs.load_rows(prov.mdl, j);
   auto step = [&](int t, const Ops& cur, Ops& nxt) __attribute__((always_inline)) {
     M4Q_NO_HOIST();
     nxt = load(t + 1 < T ? t + 1 : t);
     S ax, Brow[NU], dlt;
-    prov.rows(cur.lin, x, ax, Brow, dlt);
+    if constexpr (HOIST) prov.rows(mregs, cur.lin, x, ax, Brow, dlt);
+    else prov.rows(cur.lin, x, ax, Brow, dlt);
     const S e = csub(x, cur.xb);
     cx += dot_re(e, qrow_times<NX>(cost, t, T, e, j));
     const S* Rt = cost.r(t);
@@ -1353,7 +1366,7 @@ __device__ __forceinline__ double rollout_open(const Prov& prov, int T, S x0, co
     x = xn;
     if (store_ok) {
       Xc.st<S>((t + 1) * NX + j, x);
-      if (j == 0) stn<NU>(Uc, t * NU, u);
+      if (M4Q_STORE_ALL(NX) || j == 0) stn<NU>(Uc, t * NU, u);
     }
   };
   Ops opsA = load(0), opsB;
