@@ -32,6 +32,8 @@
 #define M4Q_TCF(n) true               // constant-target instantiation of the rollout as well (xbar loaded once): config 3 35.77 -> 35.52 ms
 #endif
 #ifndef M4Q_STORE_ALL
+// n >= 15: one wavefront per SIMD with 512 registers - loop-invariant operands of the exact mode's passes stay in registers
+#define M4Q_XH15(n) ((n) >= 15)
 #define M4Q_STORE_ALL(n) true         // values replicated over a row (k, u) are stored by every lane of the row - no exec mask to set up -
                                       // instead of by lane 0: config 4 75.5 -> 73.0 ms, config 3 together with M4Q_TC_XB_ONCE 36.05 -> 35.6
 #endif
@@ -646,6 +648,20 @@ __device__ __forceinline__ S qrow_times(const CostRef<S, TR>& cost, int t, int T
   }
 }
 
+// row j of the stage cost Q into registers (the closed loop's stage cost does not change along the horizon: index 0 serves t < T)
+template <int NX, class S, bool TR>
+__device__ __forceinline__ void load_qrow(const CostRef<S, TR>& cost, int T, int j, S (&qr)[NX]) {
+  if constexpr (TR) {
+    const S* Qt = cost.qT(0, T);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) qr[i] = Qt[i * NX + j];
+  } else {
+    const S* Qt = cost.q(0, T);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) qr[i] = Qt[j * NX + i];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Backward Riccati sweep on z = [x - xbar; 1], V = [[P, p], [p^H, pi]]  (lqr.py:28-65).
 // pi never enters a gain and is not carried.  Lane j owns column j of P and element j of p.
@@ -739,7 +755,7 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
   S tterm[PowTab<NU, Prov::ORDER_>::NP + 1];
   if constexpr (TCON) prov.target_terms(xb_next, tterm);
   // the same family: column j of Q (the closed loop's stage cost does not change along the horizon) read once per sweep
-  constexpr bool QHOIST = (HOIST_SMALL) || (HOIST && !PINNED);
+  constexpr bool QHOIST = HOIST_SMALL || HOIST;          // (n = 15 pinned sweep as well: config 4 exact 1,768 -> 1,760 ms)
   S Qcol[NX];
   if constexpr (QHOIST) {
     const S* Q0 = cost.q(0, T);
@@ -981,12 +997,32 @@ __device__ __forceinline__ void adjoint_pass(const Prov& prov, int T, const Wind
   S lam = qrow_times<NX>(cost, T, T, csub(pin.Xk.template ld<S>(T * NX + j), win.xbm.ld<S>(T * NX + j)), j);
   constexpr bool AHOIST = std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value &&
                           sizeof(S) == sizeof(double) && batch_fits<NX, NU, Prov::ORDER_>() && Prov::ORDER_ == 1;
+  // n >= 15 (one wavefront per SIMD, 512 registers): both forms of the model and Q's row stay in registers over the pass -
+  // at one wavefront per SIMD every LDS read-to-use latency is exposed
+  constexpr bool AH15 = std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && sizeof(S) == sizeof(double) && M4Q_XH15(NX) &&
+                        Prov::ORDER_ == 1;
   ModelRegs<S, NX, NU, Prov::ORDER_> mregs;
-  if constexpr (AHOIST) mregs.load_rows(prov.mdl, j);
+  S Qrow[AH15 ? NX : 1];
+  if constexpr (AH15) {
+    mregs.load(prov.mdl, j);
+    load_qrow<NX>(cost, T, j, Qrow);
+  } else if constexpr (AHOIST) {
+    mregs.load_rows(prov.mdl, j);
+  }
   auto step = [&](int t, const Ops& cur) __attribute__((always_inline)) {
     S Ac[NX], Brow[NU];
-    if constexpr (AHOIST) {
-      // (the column form held in registers as well - 24 LDS reads per index less - measured: 183-186 ms either way)
+    if constexpr (AH15) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        S a = mregs.col[0][i];
+#pragma unroll
+        for (int p = 0; p < NU; ++p) cmac_r(a, mregs.col[1 + p][i], cur.lin.u[p]);        // (order 1: monomial p is u_p)
+        Ac[i] = a;
+      }
+#pragma unroll
+      for (int k = 0; k < NU; ++k) Brow[k] = dot_lane_index<false, false, NX>(cur.lin.xg, mregs.row[1 + k]);
+    } else if constexpr (AHOIST) {
+      // (the column form held in registers as well - 24 LDS reads per index less - measured at n = 8: 183-186 ms either way)
       prov.col_batch(cur.lin, Ac);
 #pragma unroll
       for (int k = 0; k < NU; ++k) Brow[k] = dot_lane_index<false, false, NX>(cur.lin.xg, mregs.row[1 + k]);   // (order 1: monomial p is u_p)
@@ -1013,7 +1049,10 @@ __device__ __forceinline__ void adjoint_pass(const Prov& prov, int T, const Wind
       }
     }
     const S e = csub(cur.xk, cur.xb);
-    lam = dot_lane_index<false, true, NX>(lam, Ac, qrow_times<NX>(cost, t, T, e, j));   // Q_t e_t + A_t^H lam
+    S qe;
+    if constexpr (AH15) qe = dot_lane_index<false, false, NX>(e, Qrow);
+    else qe = qrow_times<NX>(cost, t, T, e, j);
+    lam = dot_lane_index<false, true, NX>(lam, Ac, qe);   // Q_t e_t + A_t^H lam
   };
   Ops ring[PF];
 #pragma unroll
@@ -1246,9 +1285,12 @@ __device__ __forceinline__ double rollout_policy(const Prov& prov, int T, S x0, 
   // (the row form of the model in registers over the rollout, as rollout_forward: n <= 9 real paths; exact mode 190 -> 184 ms with
   //  this in the policy and open rollouts and their replicated u stores unmasked: profiles/r04_ab_experiments.txt)
   constexpr bool HOIST = std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && sizeof(S) == sizeof(double) &&
-                         batch_fits<NX, NU, Prov::ORDER_>();
+                         (M4Q_XH15(NX) || batch_fits<NX, NU, Prov::ORDER_>());
   ModelRegs<S, NX, NU, Prov::ORDER_> mregs;
   if constexpr (HOIST) mregs.load_rows(prov.mdl, j);
+  constexpr bool QH = HOIST && M4Q_XH15(NX);          // (n >= 15, one wavefront per SIMD: Q's row in registers as well)
+  S Qrow[QH ? NX : 1];
+  if constexpr (QH) load_qrow<NX>(cost, T, j, Qrow);
   auto step = [&](int t, const Ops& cur, Ops& nxt) __attribute__((always_inline)) {
     M4Q_NO_HOIST();
     nxt = load(t + 1 < T ? t + 1 : t);
@@ -1256,7 +1298,8 @@ __device__ __forceinline__ double rollout_policy(const Prov& prov, int T, S x0, 
     if constexpr (HOIST) prov.rows(mregs, cur.lin, x, ax, Brow, dlt);
     else prov.rows(cur.lin, x, ax, Brow, dlt);
     const S dx = csub(x, cur.xb);
-    cx += dot_re(dx, qrow_times<NX>(cost, t, T, dx, j));
+    if constexpr (QH) cx += dot_re(dx, dot_lane_index<false, false, NX>(dx, Qrow));
+    else cx += dot_re(dx, qrow_times<NX>(cost, t, T, dx, j));
     const S* Rt = cost.r(t);
     S xn = cadd(ax, dlt);
     double un[NU], eu[NU];
@@ -1337,9 +1380,12 @@ __device__ __forceinline__ double rollout_open(const Prov& prov, int T, S x0, co
     return o;
   };
   constexpr bool HOIST = std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && sizeof(S) == sizeof(double) &&
-                         batch_fits<NX, NU, Prov::ORDER_>();
+                         (M4Q_XH15(NX) || batch_fits<NX, NU, Prov::ORDER_>());
   ModelRegs<S, NX, NU, Prov::ORDER_> mregs;
   if constexpr (HOIST) mregs.load_rows(prov.mdl, j);
+  constexpr bool QH = HOIST && M4Q_XH15(NX);
+  S Qrow[QH ? NX : 1];
+  if constexpr (QH) load_qrow<NX>(cost, T, j, Qrow);
   auto step = [&](int t, const Ops& cur, Ops& nxt) __attribute__((always_inline)) {
     M4Q_NO_HOIST();
     nxt = load(t + 1 < T ? t + 1 : t);
@@ -1347,7 +1393,8 @@ __device__ __forceinline__ double rollout_open(const Prov& prov, int T, S x0, co
     if constexpr (HOIST) prov.rows(mregs, cur.lin, x, ax, Brow, dlt);
     else prov.rows(cur.lin, x, ax, Brow, dlt);
     const S e = csub(x, cur.xb);
-    cx += dot_re(e, qrow_times<NX>(cost, t, T, e, j));
+    if constexpr (QH) cx += dot_re(e, dot_lane_index<false, false, NX>(e, Qrow));
+    else cx += dot_re(e, qrow_times<NX>(cost, t, T, e, j));
     const S* Rt = cost.r(t);
     double u[NU], eu[NU];
     S xn = cadd(ax, dlt);
