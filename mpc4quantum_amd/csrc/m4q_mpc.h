@@ -1288,7 +1288,8 @@ __device__ __forceinline__ double rollout_policy(const Prov& prov, int T, S x0, 
                          (M4Q_XH15(NX) || batch_fits<NX, NU, Prov::ORDER_>());
   ModelRegs<S, NX, NU, Prov::ORDER_> mregs;
   if constexpr (HOIST) mregs.load_rows(prov.mdl, j);
-  constexpr bool QH = HOIST && M4Q_XH15(NX);          // (n >= 15, one wavefront per SIMD: Q's row in registers as well)
+  constexpr bool QH = HOIST && M4Q_XH15(NX);          // (n >= 15, one wavefront per SIMD: Q's row in registers as well; at n = 8,
+                                                       //  two wavefronts per SIMD, the 16 registers cost more: 185 -> 190 ms)
   S Qrow[QH ? NX : 1];
   if constexpr (QH) load_qrow<NX>(cost, T, j, Qrow);
   auto step = [&](int t, const Ops& cur, Ops& nxt) __attribute__((always_inline)) {
