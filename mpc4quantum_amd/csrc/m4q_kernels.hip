@@ -226,6 +226,9 @@ constexpr int NXC = (int)(sizeof(XCUTS) / sizeof(int));
 #ifndef M4Q_WAVES_EXACT
 #define M4Q_WAVES_EXACT(S) WavesFor<S>::value
 #endif
+#ifndef M4Q_PIECE_RAW
+#define M4Q_PIECE_RAW 1
+#endif
 #ifndef M4Q_WAVES_TILE
 #define M4Q_WAVES_TILE 2
 #endif
@@ -328,6 +331,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
   // workspace of this resident row: wave-uniform base per workgroup, lane part = row within the wave
   const unsigned sX = (unsigned)(T0 + 1) * NS, sU = (unsigned)T0 * NU, sG = (unsigned)T0 * (NS + 1) * NU;
   const unsigned sXc = (unsigned)(T0 + 1) * NX;            // the SQP-guess checkpoint field: complex, NX per node
+  constexpr bool PIECE_RAW = M4Q_PIECE_RAW && sizeof(S) == sizeof(double);     // (between items of one launch: see the publish step)
   // Lanes NX..15 of a row own no column (7 of 16 at d = 3, 12 of 16 at d = 2).  Left enabled they run the sweeps on a copy of
   // column NX-1's data: harmless for the results, but the fp64 pipe spends power on them, and the clock this chip holds under an
   // fp64-dense load follows the power.  EXEC is therefore off for them during the two sweeps (every DPP source is a lane < NX;
@@ -459,19 +463,40 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
       }
       if (__any(fresh && row_begin != 0)) {
         // resume: the SQP guess, state and exit code of an earlier item or launch (fields X_GUESS/U_GUESS/XS/US/CODES).
-        // The stored guess is complex in the original basis; the basis change needs every lane (LDS exchange).
+        // From an earlier LAUNCH (or the host) the stored guess is complex in the original basis; the basis change needs every lane
+        // (LDS exchange).  From an earlier item of THIS launch (real paths) it is the working guess itself, as the item left it in
+        // the same field (PIECE_RAW: see the publish step) - a flat copy, no basis change and no rounding.
         const bool rs = fresh && row_begin != 0;
+        const bool rs_raw = PIECE_RAW && rs && later;
         double tdum = 0.0, tnew = 0.0;
-        for (int t0 = 0; t0 <= T; t0 += 8) {
-          cplx v[8];
+        if (__any(rs && !rs_raw)) {
+          for (int t0 = 0; t0 <= T; t0 += 8) {
+            cplx v[8];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) v[q] = rs ? gld(a->Xg, b * sXc + (t0 + q <= T ? t0 + q : T) * NX + jio) : czero();
-          __builtin_amdgcn_sched_barrier(0);
+            for (int q = 0; q < 8; ++q) v[q] = (rs && !rs_raw) ? gld(a->Xg, b * sXc + (t0 + q <= T ? t0 + q : T) * NX + jio) : czero();
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            if (t0 + q <= T) {
-              const S r = Basis<S, TL>::template to_state<NX, DD>(v[q], scratch, j, jj, tdum);
-              if (rs && lane_ok) Xg.st<S>((t0 + q) * NS + j, r);
+            for (int q = 0; q < 8; ++q) {
+              if (t0 + q <= T) {
+                const S r = Basis<S, TL>::template to_state<NX, DD>(v[q], scratch, j, jj, tdum);
+                if (rs && !rs_raw && lane_ok) Xg.st<S>((t0 + q) * NS + j, r);
+              }
+            }
+          }
+        }
+        if constexpr (PIECE_RAW) {
+          if (rs_raw) {
+            const M4Q_GLOBAL double* raw = (const M4Q_GLOBAL double*)(a->Xg + b * sXc);
+            constexpr int U = 12;
+            const int count = (T + 1) * NS;
+            for (int e0 = jj; e0 < count; e0 += 16 * U) {
+              double v[U];
+#pragma unroll
+              for (int u = 0; u < U; ++u) v[u] = gld(raw, e0 + 16 * u < count ? e0 + 16 * u : count - 1);
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int u = 0; u < U; ++u)
+                if (e0 + 16 * u < count) Xg.st<double>(e0 + 16 * u, v[u]);
             }
           }
         }
@@ -908,17 +933,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
     const bool finished = active && step >= row_end;
     if (__any(finished)) {
       KArgs* a = kargs();
-      // (eight nodes' loads in flight at once; the basis change of each goes through LDS)
-      for (int t0 = 0; t0 <= T; t0 += 8) {
-        S v[8];
+      // The last item of an instance publishes the guess as the host sees it: complex, original basis (eight nodes' loads in flight
+      // at once; the basis change of each goes through LDS).  An earlier item's guess is only ever read by the next item of the same
+      // launch: on the real paths it goes into the same field as it is (PIECE_RAW: (T + 1) NS doubles, flat) - 41 basis changes less
+      // on either side of every cut, and no rounding at the cuts.
+      const bool last_piece = row_end == a->step_end;
+      if (__any(finished && (!PIECE_RAW || last_piece))) {
+        for (int t0 = 0; t0 <= T; t0 += 8) {
+          S v[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = Xg.ld<S>((t0 + q <= T ? t0 + q : T) * NS + j);
-        __builtin_amdgcn_sched_barrier(0);
+          for (int q = 0; q < 8; ++q) v[q] = Xg.ld<S>((t0 + q <= T ? t0 + q : T) * NS + j);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          if (t0 + q <= T) {
-            const cplx xc = Basis<S, TL>::template to_complex<NX, DD>(v[q], tau, scratch, j, jj);
-            if (finished && lane_io) gst(a->Xg, b * sXc + (t0 + q) * NX + jio, xc);
+          for (int q = 0; q < 8; ++q) {
+            if (t0 + q <= T) {
+              const cplx xc = Basis<S, TL>::template to_complex<NX, DD>(v[q], tau, scratch, j, jj);
+              if (finished && (!PIECE_RAW || last_piece) && lane_io) gst(a->Xg, b * sXc + (t0 + q) * NX + jio, xc);
+            }
+          }
+        }
+      }
+      if constexpr (PIECE_RAW) {
+        if (finished && !last_piece) {
+          M4Q_GLOBAL double* raw = (M4Q_GLOBAL double*)(a->Xg + b * sXc);
+          constexpr int U = 12;
+          const int count = (T + 1) * NS;
+          for (int e0 = jj; e0 < count; e0 += 16 * U) {
+            double v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = Xg.ld<double>(e0 + 16 * u < count ? e0 + 16 * u : count - 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+              if (e0 + 16 * u < count) gst(raw, e0 + 16 * u, v[u]);
           }
         }
       }
