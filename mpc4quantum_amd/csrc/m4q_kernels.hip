@@ -218,8 +218,11 @@ struct ExactTile {
 // config 5's share 138.1 -> 134.7; d = 2 indifferent)
 constexpr int TC_MIN_N = 8;
 // EXACT: further cuts of an instance's run after step 2 (strictly increasing, > 2; see the kernel)
+// (round 3, when every cut cost two passes of 41 basis changes: one cut at 5.  Round 4, with the guess handed over as it is:
+//  {4, 7, 12} - config 3 185-187 ms either way, config 4 1,747 -> 1,657, config 5's share 4,315 -> 4,155; {5, 10}: 1,704 at
+//  config 4; a cut at every step 3..9: 189 ms at config 3; profiles/r04_ab_experiments.txt)
 #ifndef M4Q_EXACT_CUTS
-#define M4Q_EXACT_CUTS 5
+#define M4Q_EXACT_CUTS 4, 7, 12
 #endif
 constexpr int XCUTS[] = {M4Q_EXACT_CUTS};
 constexpr int NXC = (int)(sizeof(XCUTS) / sizeof(int));
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
     two_phase = a->step_begin < 2 && a->step_end > 2;
     // EXACT: a third piece.  The hard solves of the exact mode are the first warm steps (their shifted guess is poor: 30-130
     // active-set iterations against 1-2), so a tail [2, step_end) is as uneven as a head; cut again (XCUTS) the launch drains on the
-    // late steps' uniform one-sweep solves instead (measured on config 3: no cut 255 ms, at 8 245-247, at 6 236-239, at 5 233, at 4 244).
+    // late steps' uniform one-sweep solves instead (round 3, config 3: no cut 255 ms, at 8 245-247, at 6 236-239, at 5 233, at 4 244).
     n_pieces = two_phase ? 2 : 1;
     if constexpr (EXACT) {
 #pragma unroll
