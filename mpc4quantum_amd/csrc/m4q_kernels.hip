@@ -229,6 +229,9 @@ constexpr int NXC = (int)(sizeof(XCUTS) / sizeof(int));
 #ifndef M4Q_WAVES_EXACT
 #define M4Q_WAVES_EXACT(S) WavesFor<S>::value
 #endif
+#ifndef M4Q_UPD16
+#define M4Q_UPD16 1
+#endif
 #ifndef M4Q_PIECE_RAW
 #define M4Q_PIECE_RAW 1
 #endif
@@ -490,16 +493,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
         if constexpr (PIECE_RAW) {
           if (rs_raw) {
             const M4Q_GLOBAL double* raw = (const M4Q_GLOBAL double*)(a->Xg + b * sXc);
-            constexpr int U = 12;
             const int count = (T + 1) * NS;
-            for (int e0 = jj; e0 < count; e0 += 16 * U) {
-              double v[U];
+            if constexpr (M4Q_UPD16 && NS % 2 == 0) {
+              constexpr int U = 6;
+              for (int e0 = 2 * jj; e0 < count; e0 += 32 * U) {
+                d2_t v[U];
 #pragma unroll
-              for (int u = 0; u < U; ++u) v[u] = gld(raw, e0 + 16 * u < count ? e0 + 16 * u : count - 1);
-              __builtin_amdgcn_sched_barrier(0);
+                for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const M4Q_GLOBAL d2_t*>(raw + (e0 + 32 * u < count ? e0 + 32 * u : count - 2));
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-              for (int u = 0; u < U; ++u)
-                if (e0 + 16 * u < count) Xg.st<double>(e0 + 16 * u, v[u]);
+                for (int u = 0; u < U; ++u) {
+                  if (e0 + 32 * u < count) {
+                    const double r[2] = {v[u].x, v[u].y};
+                    stn<2>(Xg, e0 + 32 * u, r);
+                  }
+                }
+              }
+            } else {
+              constexpr int U = 12;
+              for (int e0 = jj; e0 < count; e0 += 16 * U) {
+                double v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) v[u] = gld(raw, e0 + 16 * u < count ? e0 + 16 * u : count - 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                  if (e0 + 16 * u < count) Xg.st<double>(e0 + 16 * u, v[u]);
+              }
             }
           }
         }
@@ -795,7 +815,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
     // (these small per-element passes are latency bound: unrolled so that several loads are in flight)
     // (the row's 16 lanes share the (T + 1) NS contiguous elements, and a batch of U elements per lane issues all its loads
     //  before the first store: left to the compiler the unrolled loop waited for every pair in turn - 22,000 cycles per update)
-    if (upd) {
+    if constexpr (M4Q_UPD16 && NS % 2 == 0 && sizeof(S) == sizeof(double)) {
+      // (n even: rows of the workspace start on 16-byte boundaries and hold an even number of doubles - two elements per access)
+      if (upd) {
+        constexpr int U = 6;
+        const int count = (T + 1) * NS;
+        for (int e0 = 2 * jj; e0 < count; e0 += 32 * U) {
+          double xg[U][2], xo[U][2];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int e = e0 + 32 * u < count ? e0 + 32 * u : count - 2;
+            ldn<2>(Xg, e, xg[u]);
+            ldn<2>(Xo, e, xo[u]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            if (e0 + 32 * u < count) {
+              double r[2];
+#pragma unroll
+              for (int h = 0; h < 2; ++h) r[h] = cadd(xg[u][h], cscale(csub(xo[u][h], xg[u][h]), alpha));
+              stn<2>(Xg, e0 + 32 * u, r);
+            }
+          }
+        }
+      }
+    } else if (upd) {
       constexpr int U = 12;
       const int count = (T + 1) * NS;
       for (int e0 = jj; e0 < count; e0 += 16 * U) {
@@ -811,6 +856,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
         for (int u = 0; u < U; ++u)
           if (e0 + 16 * u < count) Xg.st<S>(e0 + 16 * u, cadd(xg[u], cscale(csub(xo[u], xg[u]), alpha)));
       }
+    }
+    if constexpr (M4Q_UPD16 && NU % 2 == 0) {
+      if (upd) {
+        constexpr int V = 4;
+        const int cu = T * NU;
+        for (int e0 = 2 * jj; e0 < cu; e0 += 32 * V) {
+          double ug[V][2], uo[V][2];
+#pragma unroll
+          for (int u = 0; u < V; ++u) {
+            const int e = e0 + 32 * u < cu ? e0 + 32 * u : cu - 2;
+            ldn<2>(Ug, e, ug[u]);
+            ldn<2>(Uo, e, uo[u]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < V; ++u) {
+            if (e0 + 32 * u < cu) {
+              double r[2];
+#pragma unroll
+              for (int h = 0; h < 2; ++h) r[h] = ug[u][h] + alpha * (uo[u][h] - ug[u][h]);
+              stn<2>(Ug, e0 + 32 * u, r);
+            }
+          }
+        }
+      }
+    } else if (upd) {
       {
         constexpr int V = 8;
         const int cu = T * NU;
@@ -959,16 +1030,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
       if constexpr (PIECE_RAW) {
         if (finished && !last_piece) {
           M4Q_GLOBAL double* raw = (M4Q_GLOBAL double*)(a->Xg + b * sXc);
-          constexpr int U = 12;
           const int count = (T + 1) * NS;
-          for (int e0 = jj; e0 < count; e0 += 16 * U) {
-            double v[U];
+          if constexpr (M4Q_UPD16 && NS % 2 == 0) {
+            constexpr int U = 6;
+            for (int e0 = 2 * jj; e0 < count; e0 += 32 * U) {
+              double v[U][2];
 #pragma unroll
-            for (int u = 0; u < U; ++u) v[u] = Xg.ld<double>(e0 + 16 * u < count ? e0 + 16 * u : count - 1);
-            __builtin_amdgcn_sched_barrier(0);
+              for (int u = 0; u < U; ++u) ldn<2>(Xg, e0 + 32 * u < count ? e0 + 32 * u : count - 2, v[u]);
+              __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-              if (e0 + 16 * u < count) gst(raw, e0 + 16 * u, v[u]);
+              for (int u = 0; u < U; ++u) {
+                if (e0 + 32 * u < count) {
+                  d2_t w; w.x = v[u][0]; w.y = v[u][1];
+                  *reinterpret_cast<M4Q_GLOBAL d2_t*>(raw + e0 + 32 * u) = w;
+                }
+              }
+            }
+          } else {
+            constexpr int U = 12;
+            for (int e0 = jj; e0 < count; e0 += 16 * U) {
+              double v[U];
+#pragma unroll
+              for (int u = 0; u < U; ++u) v[u] = Xg.ld<double>(e0 + 16 * u < count ? e0 + 16 * u : count - 1);
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int u = 0; u < U; ++u)
+                if (e0 + 16 * u < count) gst(raw, e0 + 16 * u, v[u]);
+            }
           }
         }
       }
