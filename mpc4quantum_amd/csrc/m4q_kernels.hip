@@ -229,6 +229,9 @@ constexpr int NXC = (int)(sizeof(XCUTS) / sizeof(int));
 #ifndef M4Q_WAVES_EXACT
 #define M4Q_WAVES_EXACT(S) WavesFor<S>::value
 #endif
+#ifndef M4Q_LS_NODES
+#define M4Q_LS_NODES 1
+#endif
 #ifndef M4Q_UPD16
 #define M4Q_UPD16 1
 #endif
@@ -800,7 +803,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
       z.T = T; z.Xg = Xg; z.Xo = Xo; z.Xt = win.xbm; z.Ug = Ug; z.Uo = Uo; z.Ut = win.ubm;
       double al = 1.0, stepn = 0.0;
       if constexpr (TL) {
-        line_search_tl<NX, NU, DD>(z, ldsW, ldsW + 2 * NX, ldsW + 4 * NX, jj, al, stepn);     // (the host selects TL only with diagonal costs)
+        // (the host selects TL only with diagonal costs)
+        if constexpr (M4Q_LS_NODES && NS % 2 == 0) line_search_tl_nodes<NX, NU, DD, TILE>(z, ldsW, ldsW + 2 * NX, ldsW + 4 * NX, jj, al, stepn);
+        else line_search_tl<NX, NU, DD>(z, ldsW, ldsW + 2 * NX, ldsW + 4 * NX, jj, al, stepn);
       } else if (ls_diag) {
         line_search_diag<S, NX, NU, DD>(z, ldsW, ldsW + 2 * NX, ldsW + 4 * NX, jj, al, stepn);
       } else {

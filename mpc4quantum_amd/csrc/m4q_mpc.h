@@ -1941,6 +1941,122 @@ __device__ __forceinline__ void line_search_tl(const ZView<NX - 1, NU>& z, const
   step_norm = fabs(alpha) * sqrt(nrm);
 }
 
+// line_search_tl with one trajectory NODE per lane: a lane loads the n_s coordinates of guess, solution and target of its node as
+// 16-byte pairs (n_s even) and forms every slot of that node - a third of the vector-memory instructions of the slot-per-lane form
+// above, whose loads are single coordinates picked out of the nodes (the off-diagonal coordinates of a node are not contiguous).
+// Same terms, same weights; the sums run in a different order.  One node per lane and trip: two or three in flight at once cost
+// the kernel 78 / 219 spilled registers (32.2 / 37.4 ms against 29.95; profiles/r04_ab_experiments.txt).
+// TCONST: the target is the same at every node (the caller has seen QP_TARG_CONST): loaded once.
+template <int NX, int NU, int D, bool TCONST = false>
+__device__ __forceinline__ void line_search_tl_nodes(const ZView<NX - 1, NU>& z, const double* wq, const double* wqf, const double* wr,
+                                                     int jj, double& alpha, double& step_norm) {
+  constexpr int NS = NX - 1;
+  static_assert(NS % 2 == 0, "node-per-lane line search: 16-byte pairs");
+  const int T = z.T;
+  const int nxt = NX * (T + 1);
+  double num = 0.0, den = 0.0, nrm = 0.0;
+  auto weight = [&](int q) {
+    const int blk = q / (2 * NX);
+    const int r = q - blk * (2 * NX);
+    return (blk == T ? wqf : wq)[r];
+  };
+  constexpr int ROUNDS = 1;
+  double tgc[TCONST ? NS : 1];
+  if constexpr (TCONST) {
+#pragma unroll
+    for (int h = 0; h < NS / 2; ++h) {
+      double c2[2];
+      ldn<2>(z.Xt, (unsigned)(2 * h), c2);
+      tgc[2 * h] = c2[0]; tgc[2 * h + 1] = c2[1];
+    }
+  }
+  for (int t0 = jj; t0 <= T; t0 += 16 * ROUNDS) {
+    double g[ROUNDS][NS], o[ROUNDS][NS], tg[ROUNDS][NS];
+#pragma unroll
+    for (int u = 0; u < ROUNDS; ++u) {
+      const int t = t0 + 16 * u <= T ? t0 + 16 * u : T;
+#pragma unroll
+      for (int h = 0; h < NS / 2; ++h) {
+        double a2[2], b2[2], c2[2];
+        ldn<2>(z.Xg, (unsigned)(t * NS + 2 * h), a2);
+        ldn<2>(z.Xo, (unsigned)(t * NS + 2 * h), b2);
+        if constexpr (TCONST) { c2[0] = tgc[2 * h]; c2[1] = tgc[2 * h + 1]; }
+        else ldn<2>(z.Xt, (unsigned)(t * NS + 2 * h), c2);
+        g[u][2 * h] = a2[0]; g[u][2 * h + 1] = a2[1];
+        o[u][2 * h] = b2[0]; o[u][2 * h + 1] = b2[1];
+        tg[u][2 * h] = c2[0]; tg[u][2 * h + 1] = c2[1];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < ROUNDS; ++u) {
+      const int t = t0 + 16 * u;
+      const bool live = t <= T;
+      // off-diagonal slots c = a D + b, a != b: traceless coordinate c - 1
+#pragma unroll
+      for (int c = 1; c < NX; ++c) {
+        const int a = c / D, b = c - a * D;
+        if (a == b) continue;
+        const double e = g[u][c - 1] - tg[u][c - 1], d = o[u][c - 1] - g[u][c - 1];
+        const int off = a > b ? nxt : 0;            // antisymmetric coordinates live in the imaginary halves
+        double w = 0.5 * (weight(c * (T + 1) + (live ? t : T) + off) + weight((b * D + a) * (T + 1) + (live ? t : T) + off));
+        w = live ? w : 0.0;
+        num = fma(w * e, d, num);
+        den = fma(w * d, d, den);
+        nrm = fma(live ? d : 0.0, d, nrm);
+      }
+      // diagonal slots (a, a): sum_l O[a][l] r_l over the d - 1 traceless diagonal coordinates
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        double gs = 0.0, os = 0.0, ts = 0.0;
+#pragma unroll
+        for (int l = 1; l < D; ++l) {
+          const double cf = tl_coef<D>(a, l);
+          gs = fma(cf, g[u][l * D + l - 1], gs);
+          os = fma(cf, o[u][l * D + l - 1], os);
+          ts = fma(cf, tg[u][l * D + l - 1], ts);
+        }
+        const double e = gs - ts, d = os - gs;
+        const double w = live ? weight((a * D + a) * (T + 1) + t) : 0.0;
+        num = fma(w * e, d, num);
+        den = fma(w * d, d, den);
+        nrm = fma(live ? d : 0.0, d, nrm);
+      }
+    }
+  }
+  // controls: Z = [U.flatten() (k-major over (m, T)), zeros]; block b covers 2m consecutive slots
+  {
+    constexpr int U = 8;
+    const int count = NU * T;
+    for (int f0 = jj; f0 < count; f0 += 16 * U) {
+      double g[U], o[U], tg[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int f = f0 + 16 * u < count ? f0 + 16 * u : count - 1;
+        const int k = f / T, t = f - k * T;
+        g[u] = z.Ug.template ld<double>(t * NU + k);
+        o[u] = z.Uo.template ld<double>(t * NU + k);
+        tg[u] = z.Ut.template ld<double>(t * NU + k);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int f = f0 + 16 * u;
+        const double w = f < count ? wr[f % (2 * NU)] : 0.0;
+        const double e = g[u] - tg[u], d = o[u] - g[u];
+        num = fma(w * e, d, num);
+        den = fma(w * d, d, den);
+        nrm = fma(f < count ? d : 0.0, d, nrm);
+      }
+    }
+  }
+  num = rowsum<16>(num);
+  den = rowsum<16>(den);
+  nrm = rowsum<16>(nrm);
+  alpha = -num / den;
+  step_norm = fabs(alpha) * sqrt(nrm);
+}
+
 template <int NX, int NU>
 __device__ __forceinline__ void line_search(const ZView<NX, NU>& z, const double* Cq, const double* Cqf,
                                             const double* Cr, int jj, double& alpha, double& step_norm) {
