@@ -70,7 +70,7 @@ extern "C" {
 /* A traceless session with a constant target over the horizon window runs the BACKWARD sweep of the clipped solve on fp64
  * matrix-core tiles (v_mfma_f64_4x4x4_4b_f64: one member per 16-lane block, its operands fetched four horizon indices at a time,
  * csrc/m4q_tile3.h) and the rollout on DPP rows, wherever that form is built: d = 2 and d = 3 (3 and 8 traceless coordinates: at
- * d = 3 the DPP layout leaves half of every row idle) with an order-1 model.  Same results to rounding; config 3 35.5 -> 30.6 ms,
+ * d = 3 the DPP layout leaves half of every row idle) with an order-1 model.  Same results to rounding; config 3 35.5 -> 29.9 ms,
  * config 2 4.05 -> 2.9 ms, config 5's share 117.8 -> 104.4 ms (profiles/r04_ab_experiments.txt).  At d = 4 the DPP rows are full
  * and the tile form does not fit the register file (505 against 71 ms): not built.
  * The same holds for the pinned sweep of an M4Q_QP_EXACT_BOX solve (its time-batched tile form: config 3 exact 208 -> 190 ms).
