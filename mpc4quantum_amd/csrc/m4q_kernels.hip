@@ -229,6 +229,9 @@ constexpr int NXC = (int)(sizeof(XCUTS) / sizeof(int));
 #ifndef M4Q_WAVES_EXACT
 #define M4Q_WAVES_EXACT(S) WavesFor<S>::value
 #endif
+#ifndef M4Q_PUBLISH_NODES
+#define M4Q_PUBLISH_NODES 1
+#endif
 #ifndef M4Q_LS_NODES
 #define M4Q_LS_NODES 1
 #endif
@@ -1017,7 +1020,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
       // launch: on the real paths it goes into the same field as it is (PIECE_RAW: (T + 1) NS doubles, flat) - 41 basis changes less
       // on either side of every cut, and no rounding at the cuts.
       const bool last_piece = row_end == a->step_end;
-      if (__any(finished && (!PIECE_RAW || last_piece))) {
+      if constexpr (TL && M4Q_PUBLISH_NODES && NS % 2 == 0) {
+        // (traceless path, n_s even: one trajectory node per lane - its coordinates as 16-byte pairs, its NX slots formed and stored
+        //  by that lane (tl_node_to_complex) - instead of a slot per lane with an exchange through LDS per node)
+        if (finished && last_piece) {
+          for (int t = jj; t <= T; t += 16) {
+            double r[NS];
+#pragma unroll
+            for (int h = 0; h < NS / 2; ++h) {
+              double p2[2];
+              ldn<2>(Xg, (unsigned)(t * NS + 2 * h), p2);
+              r[2 * h] = p2[0]; r[2 * h + 1] = p2[1];
+            }
+            cplx out[NX];
+            tl_node_to_complex<NX, DD>(r, tau, out);
+#pragma unroll
+            for (int c = 0; c < NX; ++c) gst(a->Xg, b * sXc + t * NX + c, out[c]);
+          }
+        }
+      } else if (__any(finished && (!PIECE_RAW || last_piece))) {
         for (int t0 = 0; t0 <= T; t0 += 8) {
           S v[8];
 #pragma unroll

@@ -251,6 +251,26 @@ __device__ __forceinline__ cplx tl_to_complex(double r, double tau, cplx* scc, i
   return out;
 }
 
+// tl_to_complex of one whole trajectory node by ONE lane: r[0 .. NX-2] are the node's traceless coordinates, out[c] the NX slots of
+// vec(rho).  Same arithmetic per slot as tl_to_complex (same bits); every index is a compile-time constant.
+template <int NX, int D>
+__device__ __forceinline__ void tl_node_to_complex(const double (&r)[NX - 1], double tau, cplx (&out)[NX]) {
+  const double rs = 0.70710678118654752440;
+#pragma unroll
+  for (int c = 0; c < NX; ++c) {
+    const int a = c / D, b = c - (c / D) * D;
+    if (a == b) {
+      double v = tau * (1.0 / sqrt((double)D));
+#pragma unroll
+      for (int l = 1; l < D; ++l) v = fma(tl_coef<D>(a, l), r[l * D + l - 1], v);
+      out[c] = mk(v, 0.0);
+    } else {
+      const double own = r[c - 1], partner = r[b * D + a - 1];
+      out[c] = a < b ? mk(own * rs, -partner * rs) : mk(partner * rs, own * rs);
+    }
+  }
+}
+
 // What the closed-loop kernel calls: S, and whether the state lives in the traceless coordinates (TL).  `tau` is the member's
 // trace coordinate: written by to_state, read by to_complex (ignored unless TL).
 template <class S, bool TL> struct Basis {
