@@ -288,6 +288,11 @@ def main():
     full = args.batch or {1: 1, 2: 8192, 3: 65536, 4: 65536, 5: 2 ** 20}[args.config]
     p = configs.build(args.config, batch=full, order=args.order, offset=rank * full, total=full * world, host_models=False)
     B, n, m, T, ns = p["batch"], p["dim_x"], p["dim_u"], p["horizon"], p["n_steps"]
+    # The CPU baseline runs FIRST: its worker processes are started, and have ended, before this process loads the HIP library
+    # or makes its first HIP call (they need nothing from the GPU run; a process that holds a GPU context starts no children).
+    cpu_base = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        cpu_base = cpu_baseline(args.config, p, args.cpu_cores or usable_cores(), args.cpu_seconds)
     P = _lib.lib().m4q_library_size(p["order"], m)
     per_model = p["scales"] is not None
 
@@ -438,12 +443,13 @@ def main():
                          "hbm": {"achieved": cbytes / avg_launch_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": cbytes / avg_launch_s / 1e9 / PEAK_HBM_GBS, "compulsory_bytes": cbytes,
                                  "note": "compulsory bytes of the persistent launch (models, states and guesses once per run)"},
-                         "traffic_note": why or "FETCH_SIZE/WRITE_SIZE of profiles/r04_pmc.json, taken on this binary (launch time "
+                         "traffic_note": (why + (" (N = %d ranks: the record is keyed by the per-GPU batch and was taken on one GPU "
+                                                          "alone; frac above does not depend on it)" % joined if joined > 1 else "")) if why
+                                         else "FETCH_SIZE/WRITE_SIZE of profiles/r04_pmc.json, taken on this binary (launch time "
                                                 "within 3 %): L2-miss bytes per launch, mostly served by the Infinity Cache"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            cores = args.cpu_cores or usable_cores()
-            out["cpu_baseline"] = cpu_baseline(args.config, p, cores, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_base
         print(json.dumps(out))
     if multi:
         for sh in shard:

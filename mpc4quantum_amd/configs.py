@@ -29,12 +29,17 @@ def _targets(target_state, n_steps, horizon, dim_u):
     return X, U
 
 
-def build(config, batch=None, order=1, horizon=None, n_steps=None, offset=0, total=None, host_models=True):
+def build(config, batch=None, order=1, horizon=None, n_steps=None, offset=0, total=None, host_models=True, drift_scale=1.0,
+          r_scale=1.0):
     """Returns a dict with: name, dim_x, dim_u, order, dt, horizon, n_steps, sat, du, Q, R, Qf, x0 [B,n],
     models [B|1,n,n(1+P)], X_targ (n,cols), U_targ (m,cols-1), plant_op0 [1|B,d,d], plant_ops [1|B,m,d,d],
     generators [1+m,n,n] and scales [B,1+m] (the continuous-time operators the models come from; models is None when
     host_models=False: build them on the device).  (offset, total): this call returns members [offset, offset+batch)
-    of a `total`-member draw, so ranks of a sharded run see disjoint slices of ONE ensemble."""
+    of a `total`-member draw, so ranks of a sharded run see disjoint slices of ONE ensemble.
+    (drift_scale, r_scale), configs 3 and 5 only: the anharmonicity alpha0 (model AND plant) and the control weight R are
+    multiplied by them.  The order-1 truncation of exp(dt L) is not norm preserving (|1 + i dt alpha0| = 1.18 per step at the
+    reference's alpha0, 6e5 over T = 80: the horizon QP is then beyond fp64); drift_scale = 1/8 gives 1.003 per step
+    and r_scale = 100 keeps the controls off their bounds - the well-conditioned T = 80 case the parity tests pin strictly."""
     config = int(config)
     if config in (1, 2):
         d, m = 2, 1
@@ -79,14 +84,14 @@ def build(config, batch=None, order=1, horizon=None, n_steps=None, offset=0, tot
         B = batch or (65536 if config == 3 else 2 ** 20)
         sat = 2 * np.pi * 0.25
         du = 0.5 * sat
-        alpha0 = -2 * np.pi * 0.1 / dt
+        alpha0 = -2 * np.pi * 0.1 / dt * drift_scale
         a = np.diag(np.sqrt(np.arange(1, 3)), 1).astype(complex)
         HX = 0.5 * (a.conj().T + a)
         HY = 0.5j * (a.conj().T - a)
         P2 = _proj(3, 2)
         Qm = np.zeros((9, 9))
         Qm[0, 0] = Qm[4, 4] = 1.0
-        R = 1e-3 / sat ** 2 * np.identity(m)
+        R = r_scale * 1e-3 / sat ** 2 * np.identity(m)
         rho0 = _proj(3, 0)
         r = rx(1e-4)
         rho0[:2, :2] = r.conj().T @ rho0[:2, :2] @ r
@@ -130,6 +135,8 @@ def build(config, batch=None, order=1, horizon=None, n_steps=None, offset=0, tot
         plant0, plantk = H0[None], np.stack(Hk)[None]
     else:
         raise ValueError("config must be 1..5")
+    if (drift_scale != 1.0 or r_scale != 1.0) and config not in (3, 5):
+        raise ValueError("drift_scale / r_scale apply to configs 3 and 5")
     T = horizon or T
     ns = n_steps or ns
     X_targ, U_targ = _targets(target, ns, T, m)

@@ -1155,7 +1155,8 @@ Rccl* rccl() {
     if (!n || !*n) continue;
     r.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
     if (r.h) break;
-    r.why = dlerror();
+    const char* e = dlerror();          // NULL when no error is pending: never into a std::string as it is
+    r.why = e ? e : "dlopen failed (no dlerror text)";
   }
   if (!r.h) return &r;
   bool ok = true;

@@ -2,6 +2,8 @@
 import importlib.util
 import json
 import os
+import subprocess
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -104,6 +106,20 @@ def test_gpus_flag_starts_that_many_ranks_and_prints_one_line():
     assert json.loads(res.stdout.decode().strip())["n_gpus"] == 4
 
 
+def test_gpus_8_launch_rehearsal():
+    """The driver's own N: eight ranks, one unique-id file with eight readers, one line, LOCAL_RANK 0..7 (= the device each rank
+    opens), nothing left behind."""
+    res = _run_bench("--gpus", "8", "--launch-check")
+    assert res.returncode == 0, res.stderr.decode()
+    lines = [ln for ln in res.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and len(set(out["pids"])) == 8
+    assert [r["LOCAL_RANK"] for r in out["ranks"]] == [str(i) for i in range(8)]
+    assert all(r["WORLD_SIZE"] == "8" for r in out["ranks"]) and len({r["M4Q_UID_FILE"] for r in out["ranks"]}) == 1
+    assert not os.path.exists(out["uid_file"])
+
+
 def test_a_rank_that_dies_fails_the_launch_and_stops_its_siblings():
     import time
     t0 = time.time()
@@ -153,10 +169,11 @@ def test_committed_parity_admissions_never_cover_the_headline():
     import re
     d = json.load(open(os.path.join(ROOT, "profiles", "r04_parity_admissions.json")))
     for case, steps in d["allowed"].items():
-        m = re.match(r"stepwise\[cfg(\d)-o(\d)-B\d+-T(\d+)-(\w+)\]$", case)
+        m = re.match(r"stepwise\[cfg(\d\w?)-o(\d)-B\d+-T(\d+)-(\w+)\]$", case)
         assert m, case
-        cfg, order = int(m.group(1)), int(m.group(2))
-        assert (cfg, order) not in ((1, 1), (1, 2), (2, 1), (3, 1)), case
+        cfg, order = m.group(1), int(m.group(2))
+        # the headline, configs 1 and 2, and the two strict T = 80 cases (config 5 made well conditioned; config 5 at order 2)
+        assert (cfg, order) not in (("1", 1), ("1", 2), ("2", 1), ("3", 1), ("5w", 1), ("5", 2)), case
         assert steps == sorted(set(steps)) and all(0 <= s < 20 for s in steps)
     # every allowed step is backed by a measured record with its errors and the oracle's own sensitivity
     seen = {(r["case"], r["step"]) for r in d["measured"]}
@@ -164,3 +181,14 @@ def test_committed_parity_admissions_never_cover_the_headline():
     for r in d["measured"]:
         for e, s_k, tol in zip(r["errs"], r["oracle_sensitivity"], r["fixed_bounds"]):
             assert e <= tol + 10 * s_k
+
+
+def test_parity_admissions_tool_refuses_to_replace_a_fuller_record(tmp_path):
+    """tools/parity_admissions.py: a recording that holds fewer admissions than the committed record, or that did not execute a
+    committed case, is refused without --merge / --force (round 4 lost a measured record to a later partial run)."""
+    src = tmp_path / "measured.json"
+    src.write_text(json.dumps({"admissions": [], "cases_run": ["stepwise[cfg1-o1-B1-T10-real]"]}))
+    before = open(os.path.join(ROOT, "profiles", "r04_parity_admissions.json")).read()
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "parity_admissions.py"), str(src)], capture_output=True, text=True)
+    assert res.returncode != 0 and "refused" in res.stderr
+    assert open(os.path.join(ROOT, "profiles", "r04_parity_admissions.json")).read() == before

@@ -143,6 +143,46 @@ def test_clipped_riccati_vs_exact_box_qp():
             assert np.isclose(np.abs(Ue).max(), sat) and cc >= ce - 1e-9 and np.abs(Uc - Ue).max() > 1e-3
 
 
+def _config3_ltv_with_delta(b, T, rng):
+    """Config 3's model b (order 1) linearised along a model rollout under small random controls (Delta_t = -B_t u_t != 0,
+    Hermitian states) with a target RAMPED from the initial state to |1><1| (xbar_{t+1} != xbar_t) and a non-zero control
+    target: everything the Delta / xbar_{t+1} extension of lqr.py's sweep has to get right, at the headline's horizon."""
+    from mpc4quantum_amd import configs
+    p = configs.build(3, batch=b + 1, order=1, horizon=T)
+    n, m = 9, 2
+    mod = p["models"][b]
+    wm = orc.OracleWrapModel(mod[:, :n], mod[:, n:], m, 1)
+    ug = 0.1 * p["sat"] * rng.uniform(-1, 1, (m, T))
+    xg = np.zeros((n, T + 1), dtype=complex)
+    xg[:, 0] = p["x0"][b]
+    for t in range(T):
+        xg[:, t + 1] = wm.f(xg[:, t].reshape(-1, 1), ug[:, t]).reshape(-1)
+    A_ls, B_ls, D_ls = wm.get_model_along_traj(xg, ug, np.arange(T))
+    lam = np.linspace(0, 1, T + 1)
+    Xb = (1 - lam)[None, :] * p["x0"][b][:, None] + lam[None, :] * p["X_targ"][:, :1]
+    Ub = 0.02 * p["sat"] * rng.standard_normal((m, T))
+    return p, xg[:, 0], Xb, Ub, A_ls, B_ls, D_ls
+
+
+@pytest.mark.parametrize("r_scale", [1.0, 300.0])
+def test_affine_riccati_vs_dense_kkt_at_the_headline_horizon(r_scale):
+    """The oracle's `qp` mode - the checker of the headline arithmetic - against the independent dense KKT solve of the
+    statement at optimize.py:27-41,54 at config 3's own T = 40 (n = 9: 720 + 80 real unknowns, 720 equalities), with
+    Delta != 0, a ramped state target and a non-zero control target; bounds inactive.  (The small-T pins are
+    test_qp_mode_vs_independent_kkt on the device and test_clipped_riccati_vs_exact_box_qp above.)"""
+    rng = np.random.default_rng(17)
+    T = 40
+    for b in range(2):
+        p, x0, Xb, Ub, A_ls, B_ls, D_ls = _config3_ltv_with_delta(b, T, rng)
+        assert max(np.abs(d).max() for d in D_ls) > 1e-2 and np.abs(Xb[:, 1] - Xb[:, 0]).max() > 1e-2
+        Q_ls, R_ls = [p["Q"]] * T + [p["Qf"]], [r_scale * p["R"]] * T
+        X, U, cost, _ = orc.quad_program(x0, Xb, Ub, Q_ls, R_ls, A_ls, B_ls, D_ls, None, 1e6, None)
+        Xk, Uk = orc.kkt_quad_program(x0, Xb, Ub, Q_ls, R_ls, A_ls, B_ls, D_ls)
+        assert np.abs(Uk).max() > 0.5
+        assert np.abs(U - Uk).max() <= 1e-9 * max(1.0, np.abs(Uk).max())
+        assert np.abs(X - Xk).max() <= 1e-9 * max(1.0, np.abs(Xk).max())
+
+
 def test_exact_box_qp_oracle_satisfies_kkt():
     """The BVLS reference solution of the box-constrained QP (optimize.py:27-54) satisfies the KKT conditions of that
     statement, evaluated independently through the adjoint recursion: zero gradient on interior controls, gradient

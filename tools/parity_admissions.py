@@ -2,7 +2,12 @@
 """Turn the admissions a GPU run recorded into the committed expectation the parity tests check against.
 
     M4Q_RECORD_ADMISSIONS=1 python -m pytest tests -m gpu -q          # on the GPU box: records, asserts nothing about the list
-    python tools/parity_admissions.py [--merge]                       # gpurun_out/parity_admissions_measured.json -> profiles/r04_parity_admissions.json
+    python tools/parity_admissions.py [--merge] [--force]             # gpurun_out/parity_admissions_measured.json -> profiles/r04_parity_admissions.json
+
+Without --merge the new record REPLACES the committed one, and is refused (exit 2) when it would lose something: fewer
+admissions than the committed "measured" block holds, or a committed case the recording run did not execute ("cases_run" in the
+measured file) - a partial run (pytest -k ...) must be folded in with --merge, which touches only the cases it executed.  --force
+overrides (a kernel change that really removed admissions: say so in the commit).
 
 A teacher-forced MPC step that misses the fixed parity bounds may pass on `tol + 10 x (what the ORACLE itself moves by under a
 1e-15 perturbation of the guess the step starts from)` only if this file lists that step for that case
@@ -16,14 +21,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
-    args = [a for a in sys.argv[1:] if a != "--merge"]
+    args = [a for a in sys.argv[1:] if a not in ("--merge", "--force")]
     src = args[0] if args else os.path.join(ROOT, "gpurun_out", "parity_admissions_measured.json")
-    recs = json.load(open(src))["admissions"]
+    meas = json.load(open(src))
+    recs = meas["admissions"]
+    ran = set(meas.get("cases_run", [])) | {r["case"] for r in recs}
     dst = os.path.join(ROOT, "profiles", "r04_parity_admissions.json")
-    if "--merge" in sys.argv and os.path.exists(dst):
-        # a partial recording run (python -m pytest -k ...): cases it touched replace their records, the others keep theirs
-        seen = {r["case"] for r in recs}
-        recs = [r for r in json.load(open(dst))["measured"] if r["case"] not in seen] + recs
+    old = json.load(open(dst))["measured"] if os.path.exists(dst) else []
+    if "--merge" in sys.argv:
+        # a partial recording run (python -m pytest -k ...): cases it EXECUTED replace their records, the others keep theirs
+        recs = [r for r in old if r["case"] not in ran] + recs
+    elif "--force" not in sys.argv:
+        lost = sorted({r["case"] for r in old} - ran)
+        if lost or len(recs) < len(old):
+            sys.exit("refused: the new record (%d admissions, %d cases run) would replace a fuller one (%d admissions)%s - use "
+                     "--merge for a partial run, --force if admissions really went away"
+                     % (len(recs), len(ran), len(old), "; committed cases it did not execute: %s" % lost if lost else ""))
     allowed = {}
     for r in recs:
         allowed.setdefault(r["case"], [])
