@@ -39,6 +39,19 @@ constexpr int MODEL_ELEMS = (1 + NP) * NX * PITCH;        // per instance, eleme
 // the traceless path (m4q_mpc.h) runs the recursion on NX - 1 coordinates; everything it stages is no larger than the above
 constexpr int SCRATCH_ELEMS = (SQUARE ? DD * DD : 0) + 2 * NX;   // plant / basis-change scratch per instance (complex)
 constexpr int ROWS = 4;                                    // instances per wavefront
+// Timing-only ablations (development builds, tools/build_variant.sh ... -DM4Q_EXP=<bits>; RESULTS WRONG, never shipped - m4q_device.h
+// refuses the macro without -DM4Q_DEV).  What they bound is in profiles/r05_ab_experiments.txt.
+//   1  every line-search step stops after exactly 3 SQP iterations and no member ever fails: the work of a launch no longer depends
+//      on the numbers, so the variants below can be compared with a baseline built with bit 1 alone
+//   2  all workgroups of an XCD share ONE per-row workspace (guesses, solution, gains): every workspace access hits the L2 -
+//      the launch time that is left is what the workspace's L2 misses cost
+//   4  the four members of a workgroup share ONE model slot in LDS: the LDS footprint of a kernel whose members' models are
+//      (1 + m) shared generators - what d = 4 would need to run two wavefronts per SIMD (with -DM4Q_WAVES_REAL=2 -DM4Q_N15_HOIST=0)
+//  16  (m4q_tile3.h) the lower off-diagonal tiles of the symmetric P are copied, not computed: bound of a symmetric-P sweep
+#ifndef M4Q_EXP
+#define M4Q_EXP 0
+#endif
+constexpr int MODEL_ROWS = (M4Q_EXP & 4) ? 1 : ROWS;       // model slots per workgroup in LDS
 // the backward sweep on matrix-core tiles (m4q_tile3.h) is built where it is the faster form: d = 2, 3 (3 and 8 traceless coordinates)
 // with an order-1 library.  At d = 4 (15 coordinates = 4 x 4 tiles) it does not fit the register file (543 spilled VGPRs, 505 against
 // 71 ms on config 4) and full DPP rows leave nothing to gain; the host asks m4q_shape_*()->has_tile.
@@ -132,7 +145,7 @@ template <class S, bool TL, bool EXACT> constexpr bool exact_tile() { return EXA
 template <class S, bool TL = false, bool TILE = false, bool EXACT = false>
 constexpr size_t mpc_lds_layout_bytes() {
   constexpr int N = TL ? NX - 1 : NX;
-  return sizeof(S) * (size_t)(ROWS * model_elems<N>() + cost_elems<N>() + (cost_transposed<S, N, EXACT>() ? 2 * N * N : 0)) +
+  return sizeof(S) * (size_t)(MODEL_ROWS * model_elems<N>() + cost_elems<N>() + (cost_transposed<S, N, EXACT>() ? 2 * N * N : 0)) +
          sizeof(cplx) * (size_t)(ROWS * SCRATCH_ELEMS) + sizeof(double) * (size_t)WLS_DOUBLES + (size_t)stash_bytes<S>() +
          (TILE ? (size_t)TILE_LDS_BYTES : 0) + (exact_tile<S, TL, EXACT>() ? (size_t)(TILE_LDS_BYTES + TILE_PIN_LDS_BYTES) : 0);
 }
@@ -193,7 +206,7 @@ struct ExactTile {
     TileBackwardB<NS, NU, ORDER, true> ts;
     const int mb = ts.L.mb;
     const int dm = mb - g;
-    ts.mdl = lds_models + mb * model_elems<NS>();
+    ts.mdl = lds_models + (MODEL_ROWS == ROWS ? mb : 0) * model_elems<NS>();
     ts.T = T;
     ts.Xg = Xg; ts.Xg.off = Xg.off + (unsigned)(dm * (int)(sX * sizeof(double)));
     ts.Ug = Ug; ts.Ug.off = Ug.off + (unsigned)(dm * (int)(sU * sizeof(double)));
@@ -269,9 +282,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
   double tau = 0.0;                              // TL: the member's trace coordinate tr(rho)/sqrt(d) (row-uniform)
   constexpr bool QTR = cost_transposed<S, NS, EXACT>();
   constexpr int MODEL_K = model_elems<NS>(), COST_K = cost_elems<NS>() + (QTR ? 2 * NS * NS : 0);
-  S* mdl = lds + g * MODEL_K;
+  S* mdl = lds + (MODEL_ROWS == ROWS ? g : 0) * MODEL_K;
   scratch += g * SCRATCH_ELEMS;
-  S* ldsQ = lds + ROWS * MODEL_K;
+  S* ldsQ = lds + MODEL_ROWS * MODEL_K;
   double* ldsW = reinterpret_cast<double*>(ldsQ + COST_K);
   volatile M4Q_LDS unsigned long long* wd_slot = (volatile M4Q_LDS unsigned long long*)(ldsW + WLS_DOUBLES);
   RowStash<S> stash;
@@ -353,7 +366,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
   GView Xg, Ug, Xo, Uo, gains, Xalt, Ualt, pin_stat;
   {
     KArgs* a = kargs();
-    const long wsb = (long)blockIdx.x;
+    const long wsb = (M4Q_EXP & 2) ? (long)(blockIdx.x & 7) : (long)blockIdx.x;
     M4Q_GLOBAL S* wX = (M4Q_GLOBAL S*)a->ws_Xg;
     Xg = gview(wX, wsb * ROWS * sX, g * sX);
     Ug = gview(a->ws_Ug, wsb * ROWS * sU, g * sU);
@@ -614,7 +627,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
           TileBackwardB<NS, NU, ORDER> ts;
           const int mb = ts.L.mb;
           const int dm = mb - g;                                 // this lane's member there minus its member here
-          ts.mdl = reinterpret_cast<const double*>(lds) + mb * MODEL_K;
+          ts.mdl = reinterpret_cast<const double*>(lds) + (MODEL_ROWS == ROWS ? mb : 0) * MODEL_K;
           ts.T = T;
           ts.Xg = Xg; ts.Xg.off = Xg.off + (unsigned)(dm * (int)(sX * sizeof(double)));
           ts.Ug = Ug; ts.Ug.off = Ug.off + (unsigned)(dm * (int)(sU * sizeof(double)));
@@ -796,7 +809,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
     stash.get_x(x_meas);
     // exit code 3: non-finite objective (mpc.py:200-203).  exit code 2 (EXACT only): the solver gave up - the analogue of
     // the solver warning mpc.py:183-197 turns into code 2; either way the member's run ends here (mpc.py:196,203,231).
-    const bool fail = !finite_d(chk) || capped;
+    const bool fail = (M4Q_EXP & 1) ? false : (!finite_d(chk) || capped);
     if (solved) ++iter;
     double alpha = 1.0;
     bool fin = true;
@@ -814,7 +827,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
       } else {
         if constexpr (sizeof(S) == sizeof(cplx)) line_search<NX, NU>(z, a->Cq, a->Cqf, a->Cr, jj, al, stepn);
       }
-      if (use_ls) { alpha = al; fin = stepn < a->ls_tol; }   // mpc.py:224
+      if (use_ls) { alpha = al; fin = (M4Q_EXP & 1) ? iter >= 3 : stepn < a->ls_tol; }   // mpc.py:224
     }
     wave_sync();
     M4Q_PHASE_MARK(4)

@@ -33,7 +33,10 @@
 #endif
 #ifndef M4Q_STORE_ALL
 // n >= 15: one wavefront per SIMD with 512 registers - loop-invariant operands of the exact mode's passes stay in registers
-#define M4Q_XH15(n) ((n) >= 15)
+#ifndef M4Q_N15_HOIST
+#define M4Q_N15_HOIST 1               // 0 (experiment builds): n >= 15 compiled for TWO wavefronts per SIMD - nothing held over a sweep
+#endif
+#define M4Q_XH15(n) (M4Q_N15_HOIST && (n) >= 15)
 #define M4Q_STORE_ALL(n) true         // values replicated over a row (k, u) are stored by every lane of the row - no exec mask to set up -
                                       // instead of by lane 0: config 4 75.5 -> 73.0 ms, config 3 together with M4Q_TC_XB_ONCE 36.05 -> 35.6
 #endif
@@ -766,7 +769,7 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
   constexpr bool HOIST_SMALL = TC && sizeof(S) == sizeof(double) && NX < 15 &&
                                std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && batch_fits<NX, NU, Prov::ORDER_>();
   constexpr bool HOIST = (std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && sizeof(S) == sizeof(double) &&
-                          NX >= 15) || HOIST_SMALL;
+                          M4Q_XH15(NX)) || HOIST_SMALL;
   ModelRegs<S, NX, NU, Prov::ORDER_> mregs;
   if constexpr (HOIST) mregs.load_rows(prov.mdl, j);
   // constant target: real fused path with batched (n <= 9) or hoisted (n = 16, mode 2) model reads
@@ -1146,7 +1149,7 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
     return o;
   };
   constexpr bool HOIST = std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && sizeof(S) == sizeof(double) &&
-                         (NX >= 15 || (batch_fits<NX, NU, Prov::ORDER_>()));
+                         (M4Q_XH15(NX) || (batch_fits<NX, NU, Prov::ORDER_>()));
   ModelRegs<S, NX, NU, Prov::ORDER_> mregs;
   if constexpr (HOIST) mregs.load_rows(prov.mdl, j);
   // one horizon index: `cur` holds its operands, those of the next index are fetched into `nxt` meanwhile.  The loop

@@ -348,6 +348,11 @@ struct TileBackwardB {
         pv[I] = pn;
 #pragma unroll
         for (int J = 0; J < NT; ++J) {
+#if defined(M4Q_EXP) && (M4Q_EXP & 16)
+          // timing-only (RESULTS WRONG): the lower off-diagonal tiles of the symmetric P are not computed - what a sweep that derived
+          // them from the upper ones FOR FREE would save (the 4 x 4 transposes it would really need are not paid here)
+          if (J < I) { P[I][J] = P[J][I]; continue; }
+#endif
           double e;
           if constexpr (QLDS) e = Qlane[4 * I * NS + 4 * J];
           else e = Qt[I][J];
