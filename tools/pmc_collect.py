@@ -49,7 +49,7 @@ def bench_line(log):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tag", default="r04")
+    ap.add_argument("--tag", default="r05")
     ap.add_argument("--config", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--exact-qp", action="store_true")

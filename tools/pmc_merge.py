@@ -10,7 +10,7 @@ import os
 import shutil
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--tag", default="r04")
+ap.add_argument("--tag", default="r05")
 a = ap.parse_args()
 dst = "profiles/%s_pmc.json" % a.tag
 P = json.load(open(dst)) if os.path.exists(dst) else {}
