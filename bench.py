@@ -316,7 +316,7 @@ def main():
     # (a target that does not move over the run: the clipped sweeps take their constant-target form; not the exact mode's)
     targ_const = (not args.exact_qp) and bool(np.all(p["X_targ"] == p["X_targ"][..., :1]))
     path = sess.path()                  # "real" / "complex": the dtype of the arithmetic
-    detail = sess.path_detail()         # "complex" | "real" (d*d Hermitian coordinates) | "traceless" (d*d - 1) | "traceless-tile"
+    detail = sess.path_detail()         # "complex" | "real" (d*d Hermitian coordinates) | "traceless" (d*d - 1) | "traceless-tile" | "traceless-sg"
 
     runs = [0]
 
@@ -387,6 +387,8 @@ def main():
             key += "_real9"
         if detail == "traceless-tile":
             key += "_tile"
+        if detail == "traceless-sg":
+            key += "_sg"
         rec, why = pmc_record(key, 1e3 * avg_launch_s)
         traffic = issue = None
         if rec:
@@ -427,6 +429,7 @@ def main():
                          "kernel": "mpc_kernel<%s, PLANT_HAMILTONIAN, %s%s>" % (
                              "double" if path == "real" else "cplx", "true" if args.exact_qp else "false",
                              ", TL, TILE" if detail == "traceless-tile" and not args.exact_qp else
+                             ", TL, false, SG" if detail == "traceless-sg" else
                              ", TL" if detail in ("traceless", "traceless-tile") else ""),
                          "launches": launches, "avg_launch_ms": 1e3 * avg_launch_s,
                          "flop_per_horizon_step": executed_flop_per_hstep(n, m, P, detail, targ_const), "horizon_steps_per_launch": hsteps,

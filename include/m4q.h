@@ -79,6 +79,13 @@ extern "C" {
  * no longer an option to ask for). */
 #define M4Q_OPT_TILE 4
 #define M4Q_OPT_NO_TILE 8
+/* A traceless session whose per-member models were built by m4q_session_build_models from ONE set of generators and per-member
+ * scales, with an order-1 library - member i's model is [I + dt s_i0 L_0 | dt s_i1 L_1 | ...] (vectorize.py:8-49 at order 1) -
+ * runs the clipped solve on the shared generators wherever that form is built (d = 4): the workgroup holds one copy of dt L_k and per
+ * member only I + dt s_i0 L_0, the other scales ride on the controls; 12.6 instead of 28.8 KB of LDS per workgroup, which lets d = 4
+ * run two wavefronts per SIMD.  Same results to rounding (m4q_session_path: 4).  This bit (or M4Q_NO_SG=1 in the environment) keeps
+ * such a session on its per-member models.  Uploaded models (m4q_session_upload) always do. */
+#define M4Q_OPT_NO_SG 16
 
 /* exit codes per instance (mpc.py:130,195,202,291): 0 normal, 1 exit_condition (host side),
  * 2 solver gave up (mpc.py:183-197 turns a cvxpy/OSQP warning into this; here: an M4Q_QP_EXACT_BOX solve that stopped at
@@ -100,7 +107,7 @@ typedef struct m4q_problem {
   int32_t plant_per_instance;
   int32_t target_per_instance;
   int32_t target_cols; /* columns of X_targ; U_targ has the same count (extra ones unused) */
-  int32_t reserved;    /* options: M4Q_OPT_FORCE_COMPLEX | M4Q_OPT_NO_TRACELESS | M4Q_OPT_TILE | M4Q_OPT_NO_TILE */
+  int32_t reserved;    /* options: M4Q_OPT_FORCE_COMPLEX | M4Q_OPT_NO_TRACELESS | M4Q_OPT_TILE | M4Q_OPT_NO_TILE | M4Q_OPT_NO_SG */
   int32_t measure_freq; /* StepClock.measure_freq (mpc.py:19,252-267): the plant is measured every measure_freq-th step, the
                            model closes the loop in between; 0 or 1 = every step */
   int32_t reserved2;
@@ -217,7 +224,8 @@ M4Q_API int m4q_session_set_codes(m4q_session* s, const int32_t* codes);
 /* kernel time of the launches since the last call, from HIP events on the session stream */
 M4Q_API int m4q_session_kernel_ms(m4q_session* s, double* total_ms, int32_t* launches);
 /* arithmetic path the uploaded problem will run on: 0 complex, 1 real (Hermitian operator basis, d*d coordinates),
- * 2 real on the d*d - 1 traceless coordinates, 3 the same with the sweeps on matrix-core tiles */
+ * 2 real on the d*d - 1 traceless coordinates, 3 the same with the sweeps on matrix-core tiles, 4 the traceless clipped solve on
+ * shared generators (M4Q_OPT_NO_SG) */
 M4Q_API int m4q_session_path(const m4q_session* s);
 /* M4Q_QP_EXACT_BOX sessions: counters of the last launch - out[0] QP solves, out[1] Riccati sweeps with pinned
  * controls, out[2] ratio-test steps, out[3..5] solves ended by the KKT test / at working precision / by the iteration

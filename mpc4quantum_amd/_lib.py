@@ -19,6 +19,7 @@ OPT_FORCE_COMPLEX = 1
 OPT_NO_TRACELESS = 2
 OPT_TILE = 4
 OPT_NO_TILE = 8
+OPT_NO_SG = 16
 PLANT_NONE, PLANT_HAMILTONIAN, PLANT_GENERATOR = 0, 1, 2
 E_UNSUPPORTED, E_BADARG, E_NODEVICE, E_TIMEOUT, E_COMM = -1001, -1002, -1003, -1004, -1005
 UNIQUE_ID_BYTES = 128

@@ -44,6 +44,9 @@ struct MpcArgs {
   M4Q_P(int) head_done;                           // [B] set when an instance's head item (steps < 2) has been published; zeroed likewise
   unsigned long long deadline_ticks;        // watchdog: the launch abandons itself (queue[1] = 1) once s_memrealtime (100 MHz) has
                                             // advanced this far since the wavefront started; every wavefront reaches this exit
+  // shared-generator sessions (path 4): dt L_k on the recursion's coordinates, [1 + m][ns][ns] doubles, and the members' scales
+  // [B][1 + m]; the kernel forms A_i = I + s_i0 dt L_0 itself and never reads `models`
+  M4Q_P(const double) gens; M4Q_P(const double) scales;
 };
 
 struct LinArgs {
@@ -91,6 +94,7 @@ struct PlantArgs {
 struct ShapeOps {
   int nx, nu, order, np, d;
   int has_tile;                                                     // the tile form of the backward sweep is built for this shape (path 3)
+  int has_sg;                                                       // the shared-generator form of the clipped traceless kernel (path 4)
   int plant_only;                                                   // only plant_kernel is built (m4q_shapes.inc): serves m4q_plant_step_batch
   size_t (*mpc_lds_bytes)(int real_path, int exact_qp);
   int (*launch_mpc)(const MpcArgs&, int plant_kind, int real_path, int grid, hipStream_t);

@@ -272,7 +272,12 @@ struct m4q_session {
   const m4q::ShapeOps* mpc_ops = nullptr;      // launch_mpc / occupancy / mpc_lds_bytes: `shape`, or libm4q_hip_gen.so's for the generator plant
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  int grid = 1;
+  int grid = 1;                 // resident workgroups of the launch (paths 0-3); the per-row workspace is sized for max(grid, grid_sg)
+  int grid_sg = 0;              // ... of the shared-generator kernel (path 4: two wavefronts per SIMD at d = 4), 0 when not available
+  // shared-generator form (m4q_session_build_models with ONE generator set, order 1, traceless blocks): dt L_k on the traceless
+  // coordinates [1 + m][n-1][n-1] and the members' scales [B][1 + m]; the kernel of path 4 reads these instead of the models
+  DevBuf sg_gens, sg_scales;
+  bool sg_ok = false, no_sg = false;
   DevBuf f[M4Q_F_COUNT];
   DevBuf Cq, Cqf, Cr, Wls, wsXg, wsUg, wsG, queue, head_done;
   bool no_tile = false;
@@ -312,8 +317,11 @@ struct m4q_session {
   // the first run; m4q_session_path answers as if they were before that)
   //                         3 traceless with the backward sweep of the clipped solve / the pinned sweep of the exact solve on
   //                           matrix-core tiles (constant targets only)
+  //                         4 traceless clipped solve on shared generators (models built by m4q_session_build_models from one
+  //                           generator set; where that kernel is built: d = 4)
   int path(bool diag) const {
     if (!use_traceless(diag)) return use_real(diag) ? 1 : 0;
+    if (sg_ok && !no_sg && grid_sg > 0 && !(prob.qp_flags & M4Q_QP_EXACT_BOX) && !(prob.qp_flags & M4Q_QP_REF_LQR)) return 4;
     return (!no_tile && targ_const) ? 3 : 2;
   }
   int path() const { return path(ls_diag); }
@@ -442,7 +450,18 @@ int m4q_session_create(const m4q_problem* p, int32_t B, int32_t device, m4q_sess
   const int nquads = (B + 3) / 4;
   long resident = (long)per_cu * prop.multiProcessorCount;
   s->grid = (int)(nquads < resident ? nquads : resident);
-  const size_t rows = (size_t)s->grid * 4;
+  // the shared-generator kernel (path 4) keeps more workgroups resident than the per-member-model kernels of its shape: its own grid
+  s->no_sg = !sh->has_sg || (p->reserved & M4Q_OPT_NO_SG) != 0 || std::getenv("M4Q_NO_SG") != nullptr || exact ||
+             s->force_complex || s->no_traceless || p->order != 1;
+  if (!s->no_sg) {
+    int pc = mo->occupancy(p->plant_kind, 4, 0);
+    if (const char* cap = std::getenv("M4Q_WGS_PER_CU")) { const int v = std::atoi(cap); if (v >= 1 && v < pc) pc = v; }
+    if (pc >= 1) {
+      const long res_sg = (long)pc * prop.multiProcessorCount;
+      s->grid_sg = (int)(nquads < res_sg ? nquads : res_sg);
+    }
+  }
+  const size_t rows = (size_t)std::max(s->grid, s->grid_sg) * 4;
   // [Xg rows][Xo rows] and [Ug rows][Uo rows]; the exact QP adds [Xalt rows] and [Ualt rows][working-set rows]
   if (!rc) rc = s->wsXg.alloc((exact ? 3 : 2) * rows * (T + 1) * n * C);
   if (!rc) rc = s->wsUg.alloc((exact ? 4 : 2) * rows * T * m * 8);
@@ -584,6 +603,7 @@ int m4q_session_upload(m4q_session* s, int32_t field, const void* host, size_t b
     s->targ_const = same;
   }
   if (!s->force_complex) {
+    if (field == M4Q_F_MODELS) s->sg_ok = false;            // uploaded models: not (known to be) an ensemble of scaled shared generators
     if (field == M4Q_F_MODELS) rc = lift_upload(s, field, ch, bytes / (16 * n * n * (1 + P)), true, (int)(1 + P), s->r_models);
     if (field == M4Q_F_X0) rc = lift_upload(s, field, ch, bytes / (16 * n), false, 1, s->r_x0);
     if (field == M4Q_F_X_TARG) rc = lift_upload(s, field, ch, bytes / (16 * n), false, 1, s->r_xtarg);
@@ -697,6 +717,7 @@ int m4q_session_run(m4q_session* s, int32_t step_begin, int32_t step_end) {
   a.measure_freq = p.measure_freq > 1 ? p.measure_freq : 1;
   a.dt = p.dt; a.sat = p.sat; a.du = p.du; a.ls_tol = p.ls_tol;
   a.models = path >= 2 ? s->t_models.p : real_path ? s->r_models.p : s->f[M4Q_F_MODELS].p;
+  a.gens = (const double*)s->sg_gens.p; a.scales = (const double*)s->sg_scales.p;
   a.model_stride = p.model_per_instance ? (long)(ns * ns * (1 + P)) : 0;
   a.x0c = (const cplx*)s->f[M4Q_F_X0].p;
   a.x0s = path >= 2 ? s->t_x0.p : real_path ? s->r_x0.p : s->f[M4Q_F_X0].p;
@@ -754,7 +775,7 @@ int m4q_session_run(m4q_session* s, int32_t step_begin, int32_t step_end) {
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));
   HIP_TRY(hipEventRecord(e0, s->stream));
-  rc = s->mpc_ops->launch_mpc(a, p.plant_kind, path, s->grid, s->stream);
+  rc = s->mpc_ops->launch_mpc(a, p.plant_kind, path, path == 4 ? s->grid_sg : s->grid, s->stream);
   if (rc) return fail(rc, "mpc kernel launch failed: %s", hipGetErrorString((hipError_t)(-rc)));
   HIP_TRY(hipEventRecord(e1, s->stream));
   s->pending.emplace_back(e0, e1);
@@ -824,7 +845,7 @@ int m4q_session_info(const m4q_session* s, int64_t* hbm_bytes, int32_t* grid, in
   for (int i = 0; i < M4Q_F_COUNT; ++i) tot += (int64_t)s->f[i].bytes;
   tot += (int64_t)(s->wsXg.bytes + s->wsUg.bytes + s->wsG.bytes);
   if (hbm_bytes) *hbm_bytes = tot;
-  if (grid) *grid = s->grid;
+  if (grid) *grid = s->path() == 4 ? s->grid_sg : s->grid;
   if (lds_bytes) *lds_bytes = (int32_t)s->mpc_ops->mpc_lds_bytes(s->path(), (s->prob.qp_flags & M4Q_QP_EXACT_BOX) != 0);
   return 0;
 }
@@ -1007,6 +1028,7 @@ int m4q_session_build_models(m4q_session* s, double dt, const double* generators
   rc = s->shape->launch_discretize(a, 0, s->stream);
   if (rc) return fail(rc, "discretize launch failed");
   s->herm_ok[M4Q_F_MODELS] = false;
+  s->sg_ok = false;
   if (!s->force_complex) {
     // the same expansion in the Hermitian operator basis: lift the generators (few, or one set per member)
     const HermBasis hb(s->shape->d);
@@ -1051,6 +1073,18 @@ int m4q_session_build_models(m4q_session* s, double dt, const double* generators
           rc = s->shape->launch_discretize(q2, 2, s->stream);
           if (rc) return fail(rc, "discretize launch failed");
           s->tl_ok[M4Q_F_MODELS] = true;
+          // shared-generator form (path 4): ONE generator set, order 1 - member i's model is [I + dt s_i0 L_0 | dt s_ik L_k]; keep
+          // dt L_k on the traceless coordinates and the scales (ones when none were given)
+          if (!gen_per_instance && p.order == 1 && p.model_per_instance && !s->no_sg) {
+            std::vector<double> g(blocks.size());
+            for (size_t e = 0; e < blocks.size(); ++e) g[e] = dt * blocks[e];
+            std::vector<double> sc((size_t)s->B * (1 + m), 1.0);
+            if (scales) std::copy(scales, scales + sc.size(), sc.begin());
+            if ((rc = s->sg_gens.alloc(g.size() * 8)) || (rc = s->sg_scales.alloc(sc.size() * 8))) return rc;
+            HIP_TRY(hipMemcpy(s->sg_gens.p, g.data(), g.size() * 8, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(s->sg_scales.p, sc.data(), sc.size() * 8, hipMemcpyHostToDevice));
+            s->sg_ok = true;
+          }
         }
       }
     }

@@ -56,6 +56,11 @@ constexpr int MODEL_ROWS = (M4Q_EXP & 4) ? 1 : ROWS;       // model slots per wo
 // with an order-1 library.  At d = 4 (15 coordinates = 4 x 4 tiles) it does not fit the register file (543 spilled VGPRs, 505 against
 // 71 ms on config 4) and full DPP rows leave nothing to gain; the host asks m4q_shape_*()->has_tile.
 constexpr bool HAS_TILE = SQUARE && ORDER == 1 && NX - 1 <= 8;
+// the shared-generator form of the clipped traceless kernel (FusedProv<..., SG>, m4q_mpc.h: one set of N_k = dt L_k per workgroup, per
+// member only A_i = I + s_i0 dt L_0 and its scales) is built where the per-member models are what keeps the kernel at one wavefront
+// per SIMD: d = 4 (28.8 KB of models per workgroup against 12.6).  Sessions whose models came from m4q_session_build_models with
+// shared generators run it (path 4); the host asks m4q_shape_*()->has_sg.
+constexpr bool HAS_SG = SQUARE && ORDER == 1 && NX == 16;
 
 // register budget: waves per SIMD the kernels are compiled for (512 / budget VGPRs per lane).  d = 2 was compiled for four until the
 // end of round 3: at 128 registers every d = 2 closed-loop kernel spilled (59-372 VGPRs), and its launches are chains of
@@ -127,9 +132,9 @@ constexpr int STASH_INTS = 12;                             // per-row words of R
 // instead of a block of its own: with one the kernel needed 21,480 B of LDS, a seventh of a CU's 160 KB was 1,000 B too small for an
 // eighth workgroup, and the launch ran on 1,792 wavefronts instead of 2,048 (round 3's +3.5 % on that path until this was seen in
 // SQ_WAVE_CYCLES / GRBM_GUI_ACTIVE: 54 against 63).
-template <class S> constexpr bool stash_x_in_scratch() { return sizeof(S) == sizeof(cplx) && ROWS * SCRATCH_ELEMS >= 64; }
-template <class S> constexpr int stash_bytes() {
-  return 8 /* watchdog deadline */ + ROWS * STASH_INTS * 4 + (stash_x_in_scratch<S>() ? 0 : 64 * 16) /* x_meas, one S per lane */;
+template <class S, bool SG = false> constexpr bool stash_x_in_scratch() { return (SG || sizeof(S) == sizeof(cplx)) && ROWS * SCRATCH_ELEMS >= 64; }
+template <class S, bool SG = false> constexpr int stash_bytes() {
+  return 8 /* watchdog deadline */ + ROWS * STASH_INTS * 4 + (stash_x_in_scratch<S, SG>() ? 0 : 64 * 16) /* x_meas, one S per lane */;
 }
 
 // sizes of the staged model and costs for a recursion on N coordinates
@@ -142,11 +147,15 @@ template <class S, int N, bool EXACT> constexpr bool cost_transposed() { return 
 // the exact mode's pinned sweep runs on matrix-core tiles where the clipped mode's backward sweep does (traceless real path of a
 // shape with HAS_TILE): config 3 exact 208 -> 190 ms (profiles/r04_ab_experiments.txt)
 template <class S, bool TL, bool EXACT> constexpr bool exact_tile() { return EXACT && TL && HAS_TILE && sizeof(S) == sizeof(double); }
-template <class S, bool TL = false, bool TILE = false, bool EXACT = false>
+// SG: ROWS blocks A_i and ONE set of NP blocks N_k instead of ROWS x (1 + NP) blocks
+template <int N, bool SG> constexpr int model_lds_elems() {
+  return SG ? (ROWS + NP) * N * ModelPitch<N>::value : MODEL_ROWS * model_elems<N>();
+}
+template <class S, bool TL = false, bool TILE = false, bool EXACT = false, bool SG = false>
 constexpr size_t mpc_lds_layout_bytes() {
   constexpr int N = TL ? NX - 1 : NX;
-  return sizeof(S) * (size_t)(MODEL_ROWS * model_elems<N>() + cost_elems<N>() + (cost_transposed<S, N, EXACT>() ? 2 * N * N : 0)) +
-         sizeof(cplx) * (size_t)(ROWS * SCRATCH_ELEMS) + sizeof(double) * (size_t)WLS_DOUBLES + (size_t)stash_bytes<S>() +
+  return sizeof(S) * (size_t)(model_lds_elems<N, SG>() + cost_elems<N>() + (cost_transposed<S, N, EXACT>() ? 2 * N * N : 0)) +
+         sizeof(cplx) * (size_t)(ROWS * SCRATCH_ELEMS) + sizeof(double) * (size_t)WLS_DOUBLES + (size_t)stash_bytes<S, SG>() +
          (TILE ? (size_t)TILE_LDS_BYTES : 0) + (exact_tile<S, TL, EXACT>() ? (size_t)(TILE_LDS_BYTES + TILE_PIN_LDS_BYTES) : 0);
 }
 
@@ -254,6 +263,9 @@ constexpr int NXC = (int)(sizeof(XCUTS) / sizeof(int));
 #ifndef M4Q_PIECE_RAW
 #define M4Q_PIECE_RAW 1
 #endif
+#ifndef M4Q_WAVES_SG
+#define M4Q_WAVES_SG 2
+#endif
 #ifndef M4Q_WAVES_TILE
 #define M4Q_WAVES_TILE 2
 #endif
@@ -266,11 +278,13 @@ constexpr int NXC = (int)(sizeof(XCUTS) / sizeof(int));
 #endif
 #define M4Q_PHASE_DECL PhaseClock pc;
 #define M4Q_PHASE_MARK(i) pc.mark(i);
-template <class S, int PLANT, bool EXACT, bool TL = false, bool TILE = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_WAVES_TILE : EXACT ? M4Q_WAVES_EXACT(S) : WavesFor<S>::value, 8))) void mpc_kernel(MpcArgs) {
+template <class S, int PLANT, bool EXACT, bool TL = false, bool TILE = false, bool SG = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG ? M4Q_WAVES_SG : TILE ? M4Q_WAVES_TILE : EXACT ? M4Q_WAVES_EXACT(S) : WavesFor<S>::value, 8))) void mpc_kernel(MpcArgs) {
   static_assert(!TL || (sizeof(S) == sizeof(double) && SQUARE), "the traceless path is a real path of a d x d density matrix");
   static_assert(!TILE || (TL && !EXACT && ORDER == 1), "tile sweep: clipped solve on the traceless real coordinates, order-1 libraries");
+  static_assert(!SG || (TL && !TILE && !EXACT && ORDER == 1), "shared generators: the clipped traceless kernel of an order-1 library");
   constexpr int NS = TL ? NX - 1 : NX;
+  using Prov = FusedProv<S, NS, NU, ORDER, SG>;
   // LDS: [4 x scratch (complex)] [4 x model (S)] [Q Qf R (S)] [line-search weights] [watchdog deadline, row stash]
   cplx* scratch = reinterpret_cast<cplx*>(m4q_lds_raw);
   S* lds = reinterpret_cast<S*>(scratch + ROWS * SCRATCH_ELEMS);
@@ -281,15 +295,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
   const bool lane_ok = jj < NS, lane_io = L.lane_ok;
   double tau = 0.0;                              // TL: the member's trace coordinate tr(rho)/sqrt(d) (row-uniform)
   constexpr bool QTR = cost_transposed<S, NS, EXACT>();
-  constexpr int MODEL_K = model_elems<NS>(), COST_K = cost_elems<NS>() + (QTR ? 2 * NS * NS : 0);
-  S* mdl = lds + (MODEL_ROWS == ROWS ? g : 0) * MODEL_K;
+  // (SG: MODEL_K is one block - the member's A_i -, the NP shared blocks N_k follow the ROWS of them)
+  constexpr int MODEL_K = SG ? NS * ModelPitch<NS>::value : model_elems<NS>(), COST_K = cost_elems<NS>() + (QTR ? 2 * NS * NS : 0);
+  S* mdl = lds + (MODEL_ROWS == ROWS || SG ? g : 0) * MODEL_K;
+  S* mdn = lds + ROWS * MODEL_K;                   // (SG only)
   scratch += g * SCRATCH_ELEMS;
-  S* ldsQ = lds + MODEL_ROWS * MODEL_K;
+  S* ldsQ = lds + model_lds_elems<NS, SG>();
   double* ldsW = reinterpret_cast<double*>(ldsQ + COST_K);
   volatile M4Q_LDS unsigned long long* wd_slot = (volatile M4Q_LDS unsigned long long*)(ldsW + WLS_DOUBLES);
   RowStash<S> stash;
   stash.w = (volatile M4Q_LDS int*)(ldsW + WLS_DOUBLES + 1);
-  stash.xm = stash_x_in_scratch<S>() ? (volatile M4Q_LDS double*)m4q_lds_raw : (volatile M4Q_LDS double*)(stash.w + ROWS * STASH_INTS);
+  stash.xm = stash_x_in_scratch<S, SG>() ? (volatile M4Q_LDS double*)m4q_lds_raw : (volatile M4Q_LDS double*)(stash.w + ROWS * STASH_INTS);
   // TILE: hand-over block between the DPP-row state machine and the tile sweeps, and the G / h broadcast tiles
   volatile M4Q_LDS double* tgb = stash.xm + 64 * 2;
   volatile M4Q_LDS int* tiw = (volatile M4Q_LDS int*)(tgb + ROWS * TILE_GB_DOUBLES);
@@ -324,6 +340,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
       for (int e = threadIdx.x; e < 2 * NS * NS; e += 64) {
         const int blk = e / (NS * NS), r = (e / NS) % NS, c = e % NS;
         ldsQ[cost_elems<NS>() + e] = gld(blk ? gQf : gQ, c * NS + r);
+      }
+    }
+    if constexpr (SG) {
+      // the workgroup's copy of N_k = dt L_k (a->gens: [1 + NP][NS][NS] doubles, already scaled by dt; block 0 = dt L_0 is read
+      // per member when its A_i is formed)
+      for (int e = threadIdx.x; e < NP * NS * NS; e += 64) {
+        const int p = e / (NS * NS), r = (e / NS) % NS, c = e % NS;
+        mdn[ModelPitch<NS>::at(p, r, c)] = gld((const M4Q_GLOBAL S*)a->gens, NS * NS + e);
       }
     }
     ls_diag = a->Wls != nullptr;
@@ -393,6 +417,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
   double uprev[NU];
 #pragma unroll
   for (int k = 0; k < NU; ++k) uprev[k] = 0.0;
+  double gsc[SG ? NU : 1];     // SG: this row's member's scales of the control operators
+#pragma unroll
+  for (int k = 0; k < (SG ? NU : 1); ++k) gsc[k] = 1.0;
   BoxQpRow qp;                 // EXACT: the box-QP solve this row has in progress (spans iterations of the loop below)
   int qp_passes = 0;           // passes of this wavefront through the solver iteration (statistics)
   unsigned xt_off = 0, ut_off = 0, op0_off = 0, ops_off = 0;      // this row's member inside the per-member arrays (bytes)
@@ -408,8 +435,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
     asm volatile("" : "+s"(T));
     asm volatile("" : "+v"(Xg.off), "+v"(Ug.off), "+v"(Xo.off), "+v"(Uo.off), "+v"(gains.off));
     if constexpr (EXACT) asm volatile("" : "+v"(Xalt.off), "+v"(Ualt.off), "+v"(pin_stat.off));
-    FusedProv<S, NS, NU, ORDER> prov;
+    Prov prov;
     prov.mdl = mdl; prov.Xg = Xg; prov.Ug = Ug; prov.j = j;
+    if constexpr (SG) prov.mdn = mdn;        // (prov.sc: set after the draw below - a row may take a new member in this very pass)
+
     if (__builtin_amdgcn_s_memrealtime() > *wd_slot) {
       if (threadIdx.x == 0) __hip_atomic_store(kargs()->queue + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       break;
@@ -449,7 +478,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
       if (fresh) { pending = false; active = true; }
       wave_sync();
       if (fresh) {
-        stage_model<NS>(mdl, (const M4Q_GLOBAL S*)a->models + b * a->model_stride, jj);
+        if constexpr (SG) {
+          // A_i = I + s_i0 (dt L_0) from the shared generator; the member's other scales ride on the controls (FusedProv<..., SG>)
+          const M4Q_GLOBAL double* sc = a->scales + b * (1 + NU);
+          const double s0 = gld(sc, 0);
+#pragma unroll
+          for (int k = 0; k < NU; ++k) gsc[k] = gld(sc, 1 + k);
+
+#pragma unroll 1
+          for (int e = jj; e < NS * NS; e += 16) {
+            const int r = e / NS, c = e - r * NS;
+            mdl[ModelPitch<NS>::at(0, r, c)] = fma(s0, gld((const M4Q_GLOBAL S*)a->gens, e), r == c ? 1.0 : 0.0);
+          }
+        } else {
+          stage_model<NS>(mdl, (const M4Q_GLOBAL S*)a->models + b * a->model_stride, jj);
+        }
         xt_off = (unsigned)(b * a->xt_stride) * (unsigned)sizeof(S);
         ut_off = (unsigned)(b * a->ut_stride) * (unsigned)sizeof(double);
         op0_off = (unsigned)(b * a->op0_stride) * (unsigned)sizeof(cplx);
@@ -573,6 +616,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
       continue;
     }
     const bool running = active && step < row_end;
+    if constexpr (SG) {
+#pragma unroll
+      for (int k = 0; k < NU; ++k) prov.sc[k] = gsc[k];
+    }
 
     // ---- one QP solve per row ----
     // park what the sweeps do not need (the compiler would keep it in scratch across them)
@@ -665,7 +712,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
         if constexpr (HAS_TC) tc = (flags & QP_TARG_CONST) != 0;
         if constexpr (HAS_TC) {
           if (tc && (!MASK_IDLE || lane_ok))
-            riccati_backward<S, NS, NU, FusedProv<S, NS, NU, ORDER>, false, true>(prov, T, win, cost, flags, gains, j, st);
+            riccati_backward<S, NS, NU, Prov, false, true>(prov, T, win, cost, flags, gains, j, st);
         }
         M4Q_PHASE_MARK(3)
         if (!tc && (!MASK_IDLE || lane_ok)) riccati_backward<S, NS, NU>(prov, T, win, cost, flags, gains, j, st);
@@ -972,9 +1019,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TILE ? M4Q_W
         double tnew = 0.0;
         S rn = Basis<S, TL>::template to_state<NX, DD>(xn, scratch, j, jj, tnew);
         if (mf > 1 && __any(ok && !measure)) {
-          typename FusedProv<S, NS, NU, ORDER>::Lin lin;
+          typename Prov::Lin lin;
 #pragma unroll
-          for (int k = 0; k < NU; ++k) lin.u[k] = uapp[k];
+          for (int k = 0; k < NU; ++k) lin.u[k] = SG ? uapp[k] * gsc[k] : uapp[k];        // (SG: the provider works on the scaled controls)
           lin.xg = x_cur;
           S pred, Bdummy[NU], ddummy;
           prov.rows(lin, x_cur, pred, Bdummy, ddummy);                 // A x + N (polyu (x) x) = A_t(u) x  (model.py:81-93)
@@ -1376,6 +1423,7 @@ __global__ __launch_bounds__(64) void discretize_kernel(DiscArgs a) {
 // host-side launchers for this shape
 // ---------------------------------------------------------------------------------------------
 static size_t mpc_lds_bytes(int path, int exact) {
+  if constexpr (HAS_SG) { if (path == 4 && !exact) return mpc_lds_layout_bytes<double, true, false, false, true>(); }
   if constexpr (SQUARE) {
     if constexpr (HAS_TILE) { if (path == 3 && !exact) return mpc_lds_layout_bytes<double, true, true>(); }
     if (path >= 2) return exact ? mpc_lds_layout_bytes<double, true, false, true>() : mpc_lds_layout_bytes<double, true, false>();
@@ -1399,27 +1447,27 @@ struct LaunchOp {
   int grid;
   hipStream_t s;
   int unsupported() const { return -(int)hipErrorInvalidValue; }
-  template <class S, int PLANT, bool EXACT, bool TL, bool TILE>
+  template <class S, int PLANT, bool EXACT, bool TL, bool TILE, bool SG = false>
   int run() const {
-    const size_t lds = mpc_lds_layout_bytes<S, TL, TILE, EXACT>();
-    int rc = prep_lds(mpc_kernel<S, PLANT, EXACT, TL, TILE>, lds);
+    const size_t lds = mpc_lds_layout_bytes<S, TL, TILE, EXACT, SG>();
+    int rc = prep_lds(mpc_kernel<S, PLANT, EXACT, TL, TILE, SG>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((mpc_kernel<S, PLANT, EXACT, TL, TILE>), dim3(grid), dim3(64), lds, s, a);
+    hipLaunchKernelGGL((mpc_kernel<S, PLANT, EXACT, TL, TILE, SG>), dim3(grid), dim3(64), lds, s, a);
     return -(int)hipGetLastError();
   }
 };
 struct OccupancyOp {
   int unsupported() const { return 0; }
-  template <class S, int PLANT, bool EXACT, bool TL, bool TILE>
+  template <class S, int PLANT, bool EXACT, bool TL, bool TILE, bool SG = false>
   int run() const {
     int nb = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mpc_kernel<S, PLANT, EXACT, TL, TILE>, 64,
-                                                                 mpc_lds_layout_bytes<S, TL, TILE, EXACT>());
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mpc_kernel<S, PLANT, EXACT, TL, TILE, SG>, 64,
+                                                                 mpc_lds_layout_bytes<S, TL, TILE, EXACT, SG>());
     return e != hipSuccess ? -(int)e : nb;
   }
 };
 
-template <class S, bool EXACT, bool TL, bool TILE, class Op>
+template <class S, bool EXACT, bool TL, bool TILE, class Op, bool SG = false>
 static int pick_plant(const Op& op, int plant_kind) {
   if constexpr (!SQUARE) {
 #ifdef M4Q_VARIANT_GEN
@@ -1429,12 +1477,12 @@ static int pick_plant(const Op& op, int plant_kind) {
 #endif
   } else {
 #ifdef M4Q_VARIANT_GEN
-    if (plant_kind == PLANT_GENERATOR) return op.template run<S, PLANT_GENERATOR, EXACT, TL, TILE>();
+    if (plant_kind == PLANT_GENERATOR) return op.template run<S, PLANT_GENERATOR, EXACT, TL, TILE, SG>();
     return op.unsupported();
 #else
-    if (plant_kind == PLANT_HAMILTONIAN) return op.template run<S, PLANT_HAMILTONIAN, EXACT, TL, TILE>();
+    if (plant_kind == PLANT_HAMILTONIAN) return op.template run<S, PLANT_HAMILTONIAN, EXACT, TL, TILE, SG>();
     if (plant_kind == PLANT_GENERATOR) return op.unsupported();          // (libm4q_hip_gen.so: the host routes such sessions there)
-    return op.template run<S, PLANT_NONE, EXACT, TL, TILE>();
+    return op.template run<S, PLANT_NONE, EXACT, TL, TILE, SG>();
 #endif
   }
 }
@@ -1447,6 +1495,12 @@ static int pick_kernel(const Op& op, int plant_kind, int path, int exact, int un
   if constexpr (!SQUARE) {
     if (path || plant_kind != PLANT_NONE) return unsupported;
   }
+  if constexpr (HAS_SG) {
+    // path 4: the clipped traceless kernel on shared generators (sessions built by m4q_session_build_models; the host falls back to
+    // path 2 - per-member models - for the exact mode)
+    if (path == 4 && !exact) return pick_plant<double, false, true, false, Op, true>(op, plant_kind);
+  }
+  if (path == 4) path = 2;
   if constexpr (SQUARE) {
     if constexpr (HAS_TILE) { if (path == 3 && !exact) return pick_plant<double, false, true, true>(op, plant_kind); }
     if (path >= 2) return exact ? pick_plant<double, true, true, false>(op, plant_kind) : pick_plant<double, false, true, false>(op, plant_kind);
@@ -1544,7 +1598,7 @@ static const ShapeOps* shape_ops() {
 #else
   constexpr int plant_only = 0;
 #endif
-  static const ShapeOps ops = {NX, NU, ORDER, NP, DD, HAS_TILE ? 1 : 0, plant_only, mpc_lds_bytes, launch_mpc, launch_linearize, launch_qp, launch_plant,
+  static const ShapeOps ops = {NX, NU, ORDER, NP, DD, HAS_TILE ? 1 : 0, HAS_SG ? 1 : 0, plant_only, mpc_lds_bytes, launch_mpc, launch_linearize, launch_qp, launch_plant,
                                launch_discretize, power_list, occupancy};
   return &ops;
 }

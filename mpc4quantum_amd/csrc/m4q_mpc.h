@@ -318,40 +318,62 @@ struct ModelRegs {
   static constexpr int NP = PowTab<NU, ORDER>::NP;
   S col[1 + NP][NX];     // col[p][i] = block p, element [i][j]
   S row[1 + NP][NX];     // row[p][k] = block p, element [j][k]
-  __device__ __forceinline__ void load(const S* mdl, int j) {
+  // (P: a FusedProv - its el(p, r, k) is element [r][k] of block p wherever that block lives)
+  template <class P>
+  __device__ __forceinline__ void load(const P& pv, int j) {
 #pragma unroll
     for (int p = 0; p <= NP; ++p) {
 #pragma unroll
-      for (int i = 0; i < NX; ++i) col[p][i] = mld(mdl, ModelPitch<NX>::at(p, i, j));
+      for (int i = 0; i < NX; ++i) col[p][i] = pv.el(p, i, j);
     }
-    load_rows(mdl, j);
+    load_rows(pv, j);
   }
-  __device__ __forceinline__ void load_rows(const S* mdl, int j) {
+  template <class P>
+  __device__ __forceinline__ void load_rows(const P& pv, int j) {
 #pragma unroll
     for (int p = 0; p <= NP; ++p) {
 #pragma unroll
-      for (int k = 0; k < NX; ++k) row[p][k] = mld(mdl, ModelPitch<NX>::at(p, j, k));
+      for (int k = 0; k < NX; ++k) row[p][k] = pv.el(p, j, k);
     }
   }
 };
 
-template <class S, int NX, int NU, int ORDER>
+// SG (order-1 ensembles built from SHARED generators and per-member scales, m4q_session_build_models): member i's model is
+//   [I + dt s_i0 L_0 | dt s_i1 L_1 | ... | dt s_im L_m]                       (vectorize.py:8-49 at order 1; tests/test_mpc4quantum.py:147-188)
+// i.e. (1 + m) matrices common to every member and (1 + m) numbers of its own.  The workgroup then holds ONE copy of N_k = dt L_k
+// (`mdn`) and per member only A_i = I + s_i0 dt L_0 (`mdl`); the scales ride on the controls: with u~_k = s_ik u_k
+//   A_t = A_i + sum_k u~_k N_k,   B_t[:, k] = s_ik (N_k xg),   Delta_t = -sum_k (N_k xg) u~_k
+// - 12.6 instead of 28.8 KB of LDS per workgroup at n = 15, which is what lets d = 4 run two wavefronts per SIMD.
+template <class S, int NX, int NU, int ORDER, bool SG = false>
 struct FusedProv {
   static constexpr int ORDER_ = ORDER;
+  static constexpr bool SG_ = SG;
   static constexpr int NP = PowTab<NU, ORDER>::NP;
   static constexpr int PITCH = ModelPitch<NX>::value;
-  const S* mdl;       // LDS, [1+NP][NX][PITCH]: block 0 = A, block 1+p = N_p   (model.py:95-103)
+  static_assert(!SG || (ORDER == 1 && sizeof(S) == sizeof(double)), "shared generators: order-1 real paths");
+  const S* mdl;       // LDS, [1+NP][NX][PITCH]: block 0 = A, block 1+p = N_p   (model.py:95-103).  SG: this member's A alone
+  const S* mdn = nullptr;      // SG: LDS, [NP][NX][PITCH], the workgroup's shared N_p
+  double sc[SG ? NU : 1];     // SG: this member's scales of the control operators (row-uniform)
   GView Xg;           // guess trajectory [T+1][NX], positioned at element 0 of this instance
   GView Ug;           // [T][NU]
   int j;              // lane in row, clamped to NX-1
 
+  // element [r][k] of block p (p is a compile-time constant at every call site once the loops are unrolled)
+  __device__ __forceinline__ S el(int p, int r, int k) const {
+    if constexpr (SG) return p == 0 ? mld(mdl, ModelPitch<NX>::at(0, r, k)) : mld(mdn, ModelPitch<NX>::at(p - 1, r, k));
+    else return mld(mdl, ModelPitch<NX>::at(p, r, k));
+  }
   struct Lin {
-    double u[NU];
+    double u[NU];     // (SG: the scaled controls u~)
     S xg;
   };
   __device__ __forceinline__ Lin fetch(int t) const {
     Lin l;
     ldn<NU>(Ug, t * NU, l.u);
+    if constexpr (SG) {
+#pragma unroll
+      for (int k = 0; k < NU; ++k) l.u[k] *= sc[k];
+    }
     l.xg = Xg.ld<S>(t * NX + j);
     return l;
   }
@@ -361,9 +383,9 @@ struct FusedProv {
     po.eval(l.u);
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      S a = mld(mdl, ModelPitch<NX>::at(0, i, j));
+      S a = el(0, i, j);
 #pragma unroll
-      for (int p = 0; p < NP; ++p) cmac_r(a, mld(mdl, ModelPitch<NX>::at(1 + p, i, j)), po.pu[p]);
+      for (int p = 0; p < NP; ++p) cmac_r(a, el(1 + p, i, j), po.pu[p]);
       Ac[i] = a;
     }
   }
@@ -375,7 +397,7 @@ struct FusedProv {
 #pragma unroll
     for (int p = 0; p <= NP; ++p) {
 #pragma unroll
-      for (int i = 0; i < NX; ++i) col[p][i] = mld(mdl, ModelPitch<NX>::at(p, i, j));
+      for (int i = 0; i < NX; ++i) col[p][i] = el(p, i, j);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -389,7 +411,7 @@ struct FusedProv {
   // col() and rows() from registers loaded in one batch (real path of the backward sweep)
   __device__ __forceinline__ void col_rows(const Lin& l, S v, S (&Ac)[NX], S& av, S (&Brow)[NU], S& dlt) const {
     ModelRegs<S, NX, NU, ORDER> r;
-    r.load(mdl, j);
+    r.load(*this, j);
     __builtin_amdgcn_sched_barrier(0);
     col_rows(r, l, v, Ac, av, Brow, dlt);
   }
@@ -434,7 +456,7 @@ struct FusedProv {
     for (int p = 0; p <= NP; ++p) {
       S row[NX];
 #pragma unroll
-      for (int k = 0; k < NX; ++k) row[k] = mld(mdl, ModelPitch<NX>::at(p, j, k));
+      for (int k = 0; k < NX; ++k) row[k] = el(p, j, k);
       tt[p] = dot_lane_index<false, false, NX>(xbar, row);
     }
   }
@@ -451,12 +473,12 @@ struct FusedProv {
 #pragma unroll
     for (int p = 0; p <= NP; ++p) {
 #pragma unroll
-      for (int i = 0; i < NX; ++i) col[p][i] = mld(mdl, ModelPitch<NX>::at(p, i, j));
+      for (int i = 0; i < NX; ++i) col[p][i] = el(p, i, j);
     }
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
 #pragma unroll
-      for (int k = 0; k < NX; ++k) row[p][k] = mld(mdl, ModelPitch<NX>::at(1 + p, j, k));
+      for (int k = 0; k < NX; ++k) row[p][k] = el(1 + p, j, k);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -482,6 +504,21 @@ struct FusedProv {
     av = av_from_terms(po, tt);
     finish_rows(l, po, nx, Brow, dlt);
   }
+  // ... with the N_p rows read from LDS one at a time (n = 15 at two wavefronts per SIMD: neither a batch nor a hoist fits)
+  __device__ __forceinline__ void rows_tc_lds(const Lin& l, const S (&tt)[1 + NP], S& av, S (&Brow)[NU], S& dlt) const {
+    Poly<NU, ORDER> po;
+    po.eval(l.u);
+    S nx[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      S row[NX];
+#pragma unroll
+      for (int k = 0; k < NX; ++k) row[k] = el(1 + p, j, k);
+      nx[p] = dot_lane_index<false, false, NX>(l.xg, row);
+    }
+    av = av_from_terms(po, tt);
+    finish_rows(l, po, nx, Brow, dlt);
+  }
   __device__ __forceinline__ void finish_rows(const Lin& l, const Poly<NU, ORDER>& po, const S (&nx)[NP], S (&Brow)[NU], S& dlt) const {
     dlt = zero_of<S>();
 #pragma unroll
@@ -493,8 +530,9 @@ struct FusedProv {
 #pragma unroll
         for (int p = 0; p < NP; ++p) cmac_r(b, nx[p], po.dpu[k][p]);
       }
-      Brow[k] = b;
       cmac_r(dlt, b, -l.u[k]);
+      if constexpr (SG) b = cscale(b, sc[k]);
+      Brow[k] = b;
     }
   }
   // row j of B_t alone (the adjoint pass needs neither A_t v nor Delta_t)
@@ -504,8 +542,9 @@ struct FusedProv {
       for (int k = 0; k < NU; ++k) {
         S row[NX];
 #pragma unroll
-        for (int c = 0; c < NX; ++c) row[c] = mld(mdl, ModelPitch<NX>::at(1 + k, j, c));
+        for (int c = 0; c < NX; ++c) row[c] = el(1 + k, j, c);
         Brow[k] = dot_lane_index<false, false, NX>(l.xg, row);          // monomial p is u_p (order1_is_identity)
+        if constexpr (SG) Brow[k] = cscale(Brow[k], sc[k]);
       }
     } else {
       S av, dlt;
@@ -523,7 +562,7 @@ struct FusedProv {
 #pragma unroll
       for (int p = 0; p <= NP; ++p) {
 #pragma unroll
-        for (int k = 0; k < NX; ++k) row[p][k] = mld(mdl, ModelPitch<NX>::at(p, j, k));
+        for (int k = 0; k < NX; ++k) row[p][k] = el(p, j, k);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -538,13 +577,13 @@ struct FusedProv {
       //   av = sum_k lane_k(v) A_t[j][k],   nx[p] = sum_k lane_k(xg) N_p[j][k]
       S arow[NX];
 #pragma unroll
-      for (int k = 0; k < NX; ++k) arow[k] = mld(mdl, ModelPitch<NX>::at(0, j, k));
+      for (int k = 0; k < NX; ++k) arow[k] = el(0, j, k);
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         S nrow[NX];
 #pragma unroll
         for (int k = 0; k < NX; ++k) {
-          nrow[k] = mld(mdl, ModelPitch<NX>::at(1 + p, j, k));
+          nrow[k] = el(1 + p, j, k);
           cmac_r(arow[k], nrow[k], po.pu[p]);
         }
         nx[p] = dot_lane_index<false, false, NX>(l.xg, nrow);
@@ -558,10 +597,10 @@ struct FusedProv {
       static_for<0, NX>([&](auto kk) {
         constexpr int k = decltype(kk)::value;
         S own[NP + 1];
-        own[NP] = mld(mdl, ModelPitch<NX>::at(0, j, k));
+        own[NP] = el(0, j, k);
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-          own[p] = mld(mdl, ModelPitch<NX>::at(1 + p, j, k));
+          own[p] = el(1 + p, j, k);
           cmac_r(own[NP], own[p], po.pu[p]);
         }
         emit_terms<IdxSameLaneVec<k>, false, false, false, 0, NP + 1>(accs, srcs, own);
@@ -581,10 +620,16 @@ struct FusedProv {
 #pragma unroll
         for (int p = 0; p < NP; ++p) cmac_r(b, nx[p], po.dpu[k][p]);
       }
-      Brow[k] = b;
       cmac_r(dlt, b, -l.u[k]);
+      if constexpr (SG) b = cscale(b, sc[k]);
+      Brow[k] = b;
     }
   }
+};
+// is this provider a FusedProv, and of which kind
+template <class P> struct fused_kind { static constexpr bool any = false, sg = false; };
+template <class S, int NX, int NU, int ORDER, bool SG> struct fused_kind<FusedProv<S, NX, NU, ORDER, SG>> {
+  static constexpr bool any = true, sg = SG;
 };
 
 template <int NX, int NU>
@@ -757,7 +802,7 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
   auto load = [&](int t) __attribute__((always_inline)) {
     Ops o;
     o.lin = prov.fetch(t);
-    if constexpr (TC && M4Q_TC_XB_ONCE(NX)) o.xb = xb_next;            // (constant target: the column loaded above serves every index)
+    if constexpr (TC && (M4Q_TC_XB_ONCE(NX) || fused_kind<Prov>::sg)) o.xb = xb_next;   // (constant target: the column loaded above serves every index)
     else o.xb = win.xbm.ld<S>(t * NX + j);
     ldn<NU>(win.ubm, t * NU, o.ub);
     if constexpr (PINNED) ldn<NU>(pin->stat, t * NU, o.stv);
@@ -766,15 +811,17 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
   // n = 16 real path: one wavefront per SIMD owns all 512 registers, and alone on its SIMD it cannot hide the LDS
   // read-to-use latency of the model at every horizon index: the ROW form of the model is read once per sweep and kept in
   // registers (measured A/B on config 4: 92.9 -> 85.8 ms; profiles/r02_ab_experiments.txt)
+  // (a shared-generator provider, FusedProv<..., SG>, is compiled for two wavefronts per SIMD at n = 15: nothing is held over a sweep)
   constexpr bool HOIST_SMALL = TC && sizeof(S) == sizeof(double) && NX < 15 &&
                                std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && batch_fits<NX, NU, Prov::ORDER_>();
   constexpr bool HOIST = (std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && sizeof(S) == sizeof(double) &&
                           M4Q_XH15(NX)) || HOIST_SMALL;
   ModelRegs<S, NX, NU, Prov::ORDER_> mregs;
-  if constexpr (HOIST) mregs.load_rows(prov.mdl, j);
+  if constexpr (HOIST) mregs.load_rows(prov, j);
   // constant target: real fused path with batched (n <= 9) or hoisted (n = 16, mode 2) model reads
-  constexpr bool TCON = TC && std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && sizeof(S) == sizeof(double) &&
-                        ((batch_fits<NX, NU, Prov::ORDER_>()) || HOIST);
+  constexpr bool TCON = TC && sizeof(S) == sizeof(double) &&
+                        ((std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && ((batch_fits<NX, NU, Prov::ORDER_>()) || HOIST)) ||
+                         fused_kind<Prov>::sg);
   S tterm[PowTab<NU, Prov::ORDER_>::NP + 1];
   if constexpr (TCON) prov.target_terms(xb_next, tterm);
   // the same family: column j of Q (the closed loop's stage cost does not change along the horizon) read once per sweep
@@ -802,6 +849,9 @@ __device__ __forceinline__ void riccati_backward(const Prov& prov, int T, const 
     } else if constexpr (TCON && HOIST) {
       prov.col(lin, Ac);                       // (its 60 LDS reads as one batch: no change, 71.3 ms either way)
       prov.rows_tc(mregs, lin, tterm, ax, Brow, dlt);
+    } else if constexpr (TCON && fused_kind<Prov>::sg) {
+      prov.col(lin, Ac);
+      prov.rows_tc_lds(lin, tterm, ax, Brow, dlt);
     } else if constexpr (TCON) {
       prov.col_rows_tc(lin, tterm, Ac, ax, Brow, dlt);
     } else if constexpr (HOIST) {
@@ -1027,10 +1077,10 @@ __device__ __forceinline__ void adjoint_pass(const Prov& prov, int T, const Wind
   ModelRegs<S, NX, NU, Prov::ORDER_> mregs;
   S Qrow[AH15 ? NX : 1];
   if constexpr (AH15) {
-    mregs.load(prov.mdl, j);
+    mregs.load(prov, j);
     load_qrow<NX>(cost, T, j, Qrow);
   } else if constexpr (AHOIST) {
-    mregs.load_rows(prov.mdl, j);
+    mregs.load_rows(prov, j);
   }
   auto step = [&](int t, const Ops& cur) __attribute__((always_inline)) {
     S Ac[NX], Brow[NU];
@@ -1151,7 +1201,7 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
   constexpr bool HOIST = std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && sizeof(S) == sizeof(double) &&
                          (M4Q_XH15(NX) || (batch_fits<NX, NU, Prov::ORDER_>()));
   ModelRegs<S, NX, NU, Prov::ORDER_> mregs;
-  if constexpr (HOIST) mregs.load_rows(prov.mdl, j);
+  if constexpr (HOIST) mregs.load_rows(prov, j);
   // one horizon index: `cur` holds its operands, those of the next index are fetched into `nxt` meanwhile.  The loop
   // below runs two indices per trip with the two operand sets swapping roles, so that no set is ever copied.
   // (Fetching two indices ahead with three rotating sets was measured: +1.6 %, profiles/r02_ab_experiments.txt.)
@@ -1310,7 +1360,7 @@ __device__ __forceinline__ double rollout_policy(const Prov& prov, int T, S x0, 
   constexpr bool HOIST = std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && sizeof(S) == sizeof(double) &&
                          (M4Q_XH15(NX) || batch_fits<NX, NU, Prov::ORDER_>());
   ModelRegs<S, NX, NU, Prov::ORDER_> mregs;
-  if constexpr (HOIST) mregs.load_rows(prov.mdl, j);
+  if constexpr (HOIST) mregs.load_rows(prov, j);
   constexpr bool QH = HOIST && M4Q_XH15(NX);          // (n >= 15, one wavefront per SIMD: Q's row in registers as well; at n = 8,
                                                        //  two wavefronts per SIMD, the 16 registers cost more: 185 -> 190 ms)
   S Qrow[QH ? NX : 1];
@@ -1406,7 +1456,7 @@ __device__ __forceinline__ double rollout_open(const Prov& prov, int T, S x0, co
   constexpr bool HOIST = std::is_same<Prov, FusedProv<S, NX, NU, Prov::ORDER_>>::value && sizeof(S) == sizeof(double) &&
                          (M4Q_XH15(NX) || batch_fits<NX, NU, Prov::ORDER_>());
   ModelRegs<S, NX, NU, Prov::ORDER_> mregs;
-  if constexpr (HOIST) mregs.load_rows(prov.mdl, j);
+  if constexpr (HOIST) mregs.load_rows(prov, j);
   constexpr bool QH = HOIST && M4Q_XH15(NX);
   S Qrow[QH ? NX : 1];
   if constexpr (QH) load_qrow<NX>(cost, T, j, Qrow);

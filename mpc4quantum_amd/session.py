@@ -18,7 +18,7 @@ class EnsembleSession:
     def __init__(self, B, dim_x, dim_u, order, horizon, n_steps, dt, sat, du=None, max_iter=100, warm_start=True,
                  qp_flags=None, plant_kind=_lib.PLANT_HAMILTONIAN, model_per_instance=False, plant_per_instance=False,
                  target_per_instance=False, target_cols=None, ls_tol=1e-4, device=-1, force_complex=False, measure_freq=1,
-                 exact_qp=False, traceless=True, tile=None):
+                 exact_qp=False, traceless=True, tile=None, shared_generators=None):
         """exact_qp: solve every QP of the loop to the box-constrained optimum (M4Q_QP_EXACT_BOX, what the reference's OSQP
         call converges to) instead of clipping the Riccati rollout."""
         if sat is None:
@@ -36,8 +36,10 @@ class EnsembleSession:
         # traceless=False keeps a real-path session on its d*d coordinates (M4Q_OPT_NO_TRACELESS) instead of the d*d - 1 traceless ones
         # tile: None / True = the library's choice (the backward sweep on matrix-core tiles where that form is built: d = 2, 3 with an
         # order-1 model, whenever the target is constant over the window), False = DPP sweeps (M4Q_OPT_NO_TILE)
+        # shared_generators: None / True = the library's choice (models built by build_models from ONE generator set at order 1 run the
+        # clipped traceless solve on the shared generators where that kernel is built: d = 4), False = per-member models (M4Q_OPT_NO_SG)
         p.reserved = (_lib.OPT_FORCE_COMPLEX if force_complex else 0) | (0 if traceless else _lib.OPT_NO_TRACELESS) | \
-            (_lib.OPT_NO_TILE if tile is False else 0)
+            (_lib.OPT_NO_TILE if tile is False else 0) | (_lib.OPT_NO_SG if shared_generators is False else 0)
         p.measure_freq = int(measure_freq)
         p.dt, p.sat, p.du, p.ls_tol = float(dt), float(sat), float(du if du is not None else 0.0), float(ls_tol)
         self.problem = p
@@ -130,8 +132,8 @@ class EnsembleSession:
     def path_detail(self):
         """'complex', 'real' (d*d Hermitian coordinates), 'traceless' (the d*d - 1 traceless Hermitian coordinates) or
         'traceless-tile' (the same with the backward sweep of the clipped solve / the pinned sweep of the exact solve on fp64
-        matrix-core tiles)."""
-        return ("complex", "real", "traceless", "traceless-tile")[_lib.check(self._L.m4q_session_path(self._h))]
+        matrix-core tiles), or 'traceless-sg' (the traceless clipped solve on shared generators and per-member scales)."""
+        return ("complex", "real", "traceless", "traceless-tile", "traceless-sg")[_lib.check(self._L.m4q_session_path(self._h))]
 
     def info(self):
         hbm = C.c_int64()

@@ -730,7 +730,7 @@ def _build_cfg(cfg, **kw):
     return configs.build(cfg, **kw)
 
 
-@pytest.mark.parametrize("path", ["real", "complex", "real9", "tile"])
+@pytest.mark.parametrize("path", ["real", "complex", "real9", "tile", "sg"])
 @pytest.mark.parametrize("cfg,order,batch,horizon", [(1, 1, 1, None), (1, 2, 1, None), (2, 1, 3, None), (3, 1, 4, None),
                                                       (3, 2, 2, None), (4, 1, 2, 12), (4, 1, 2, None), (5, 1, 2, None),
                                                       ("5w", 1, 2, None), ("5d", 1, 2, None), (5, 2, 2, None)])
@@ -740,7 +740,8 @@ def test_closed_loop_stepwise_teacher_forced(cfg, order, batch, horizon, path):
     QP-solve count - must match to 1e-10 whatever the conditioning of the loop; the shifted SQP
     guesses (the far end of a stiff 40-step horizon) to 1e-7.  horizon None = the BASELINE config's own size: every config
     runs at its own T (config 2: 20, configs 3 and 4: 40, config 5: 80) for all of its 20 MPC steps.
-    Paths: "real" = the d*d - 1 traceless Hermitian coordinates on DPP rows (M4Q_OPT_NO_TILE), "real9" = the d*d Hermitian
+    Paths: "sg" = the traceless clipped solve on shared generators and per-member scales (models from build_models; d = 4),
+    "real" = the d*d - 1 traceless Hermitian coordinates on DPP rows (M4Q_OPT_NO_TILE), "real9" = the d*d Hermitian
     coordinates (M4Q_OPT_NO_TRACELESS), "tile" = traceless with the backward sweep on matrix-core tiles (what a Liouvillian
     model with a constant target gets by default at d = 2, 3),
     "complex" = the general path.  A step may exceed the fixed bounds only by ten times what the ORACLE itself moves when the
@@ -753,6 +754,8 @@ def test_closed_loop_stepwise_teacher_forced(cfg, order, batch, horizon, path):
     saturating) holds us[k], xs[k+1] to 1e-10 on every step; only the guesses it leaves behind may use the clause."""
     if path == "real9" and (cfg, order, horizon) not in ((2, 1, None), (3, 1, None), (4, 1, 12)):
         pytest.skip("the d*d-coordinate real path is exercised on one configuration per dimension")
+    if path == "sg" and not (order == 1 and cfg == 4):
+        pytest.skip("the shared-generator kernel exists at d = 4 with an order-1 model (config 4 at T = 12 and at its own T = 40)")
     if path == "tile" and not (order == 1 and cfg in (1, 2, 3, 5, "5w", "5d")):
         pytest.skip("the tile sweep exists at d = 2, 3 with an order-1 model (every such configuration runs it here)")
     p = _build_cfg(cfg, batch=max(batch, 4) if cfg == 3 else batch, order=order, horizon=horizon)
@@ -767,9 +770,14 @@ def test_closed_loop_stepwise_teacher_forced(cfg, order, batch, horizon, path):
     ns, T = p["n_steps"], p["horizon"]
     sess = _session(q, batch, force_complex=(path == "complex"), traceless=(path != "real9"), tile=(path == "tile"))
     try:
-        sess.load_problem(models, p["x0"][idx], p["X_targ"], p["U_targ"], p["Q"], p["R"], p["Qf"], p["plant_op0"],
-                          p["plant_ops"])
-        assert sess.path_detail() == {"real": "traceless", "real9": "real", "tile": "traceless-tile", "complex": "complex"}[path]
+        if path == "sg":
+            # the models built on the device from the shared generators and the members' scales: the kernel of path 4 works on
+            # the generators themselves ("sg"); the oracle above on the host-built models of the same members
+            sess.build_models(p["dt"], p["generators"], p["scales"][idx])
+        sess.load_problem(None if path == "sg" else models, p["x0"][idx], p["X_targ"], p["U_targ"], p["Q"], p["R"], p["Qf"],
+                          p["plant_op0"], p["plant_ops"])
+        assert sess.path_detail() == {"real": "traceless", "real9": "real", "tile": "traceless-tile", "complex": "complex",
+                                      "sg": "traceless-sg"}[path]
         xs_t, us_t = np.swapaxes(xs, 1, 2), np.swapaxes(us, 1, 2)          # time-major, as the C ABI holds them
         key = "stepwise[cfg%s-o%d-B%d-T%d-%s]" % (cfg, order, batch, T, path)
         _CASES_RUN.add(key)
@@ -1633,6 +1641,63 @@ def test_arithmetic_path_selection():
         M = rng.standard_normal((9, 9)) + 1j * rng.standard_normal((9, 9))
         q["Q"] = q["Q"] + 0.05 * (M @ M.conj().T)
     assert detail(dense_complex_cost) == "complex"
+
+
+def test_shared_generator_path_selection_and_agreement():
+    """Path 4 (M4Q_OPT_NO_SG): a d = 4 session whose models come from m4q_session_build_models with ONE generator set runs the
+    clipped traceless solve on the shared generators - same results as the per-member-model kernel to the loop's own sensitivity,
+    identical QP-solve counts, repeated launches bit-identical; uploaded models, the exact mode, lqr.py's mode and the opt-out stay
+    on per-member models; shapes without that kernel (d = 3) are unaffected."""
+    B = 64
+    p = configs.build(4, batch=B, horizon=16, n_steps=8)
+    # config 4 scales only the drift (J_i); give every member its own drive scales as well, so that the scales that ride on the
+    # controls (u~_k = s_ik u_k, B_t = s_ik N_k xg) are exercised - models of the oracle and of the uploaded-model runs rebuilt to match
+    rng = np.random.default_rng(44)
+    p["scales"] = np.concatenate([p["scales"][:, :1], 1 + 0.05 * rng.standard_normal((B, 3))], axis=1)
+    p["models"] = np.ascontiguousarray(m4q.discretize_homogeneous(
+        [p["scales"][:, k, None, None] * p["generators"][k][None] for k in range(4)], p["dt"], 1))
+
+    def run(build, **kw):
+        sess = _session(p, B, **kw)
+        try:
+            if build:
+                sess.build_models(p["dt"], p["generators"], p["scales"])
+            sess.load_problem(None if build else p["models"], p["x0"], p["X_targ"], p["U_targ"], p["Q"], p["R"], p["Qf"],
+                              p["plant_op0"], p["plant_ops"])
+            sess.run(0, p["n_steps"])
+            a = sess.results()
+            sess.run(0, p["n_steps"])
+            b = sess.results()
+            for key in ("xs", "us", "qp_solves", "exit_codes"):
+                assert np.array_equal(a[key], b[key]), key
+            a["xs"], a["us"] = np.swapaxes(a["xs"], 1, 2), np.swapaxes(a["us"], 1, 2)        # (B, n, steps + 1), (B, m, steps)
+            return sess.path_detail(), a, sess.info()
+        finally:
+            sess.close()
+    d_sg, r_sg, i_sg = run(True)
+    assert d_sg == "traceless-sg"
+    d_pm, r_pm, i_pm = run(True, shared_generators=False)
+    assert d_pm == "traceless"
+    assert i_sg["lds_bytes"] < i_pm["lds_bytes"] and i_sg["lds_bytes"] <= 20480       # eight workgroups per CU: two wavefronts per SIMD
+    assert run(False)[0] == "traceless"                                                 # uploaded models
+    assert run(True, exact_qp=True)[0] == "traceless"
+    assert run(True, qp_flags=_lib.QP_REF_LQR)[0] == "real"
+    assert np.all(r_sg["exit_codes"] == 0) and np.array_equal(r_sg["qp_solves"], r_pm["qp_solves"])
+    assert rel(r_sg["us"][:, :, 0], r_pm["us"][:, :, 0]) <= 1e-10 and rel(r_sg["xs"][:, :, 1], r_pm["xs"][:, :, 1]) <= 1e-10
+    idx = np.arange(4)
+    xs, us, codes, solves = _oracle_batch(p, idx)
+    eu, ex = _envelope(p, idx, xs, us)
+    assert np.array_equal(r_sg["qp_solves"][idx], solves)
+    assert np.all(np.abs(r_sg["us"][idx] - us).max(axis=(0, 1)) <= 1e-9 + 100 * eu)
+    assert np.all(np.abs(r_sg["xs"][idx] - xs).max(axis=(0, 1))[1:] <= 1e-9 + 100 * ex[1:])
+    q3 = configs.build(3, batch=4, horizon=8, n_steps=3)
+    s3 = _session(q3, 4)
+    try:
+        s3.build_models(q3["dt"], q3["generators"], q3["scales"])
+        s3.load_problem(None, q3["x0"], q3["X_targ"], q3["U_targ"], q3["Q"], q3["R"], q3["Qf"], q3["plant_op0"], q3["plant_ops"])
+        assert s3.path_detail() == "traceless-tile"
+    finally:
+        s3.close()
 
 
 def test_mpc_batch_sharded_rccl_single_rank(tmp_path):

@@ -95,6 +95,8 @@ def main():
         key += "_real9"
     if wl.endswith("(traceless-tile)"):
         key += "_tile"
+    if wl.endswith("(traceless-sg)"):
+        key += "_sg"
     stats_ms = None
     for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
         rows = list(csv.DictReader(open(f)))
