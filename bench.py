@@ -34,7 +34,7 @@ PEAK_F64_TFLOPS = 78.6      # MI355X fp64 dense rate (AMD spec; 256 CU x 4 SIMD 
                             # DPP row broadcasts) and v_mfma_f64 run on the SAME pipe at the same rate: tools/ubench_mfma.hip measures
                             # 76-78 TFLOP/s for either and the SUM when both are issued (profiles/r02_ubench_mfma.txt)
 PEAK_HBM_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md
-PMC_JSON = os.path.join(ROOT, "profiles", "r04_pmc.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r05_pmc.json")
 
 
 def mac_per_hstep(n, m, P):
@@ -67,12 +67,12 @@ def compulsory_bytes(B, n, m, P, T, ns, path):
 
 
 def pmc_record(key, avg_launch_ms):
-    """Counter record of this exact configuration from profiles/r04_pmc.json (tools/pmc_collect.py), or (None, why).  Refused when
+    """Counter record of this exact configuration from profiles/r05_pmc.json (tools/pmc_collect.py), or (None, why).  Refused when
     the launch it was taken on differs from the one measured now by more than 3 %: counters describe a binary, not a config."""
     try:
         rec = json.load(open(PMC_JSON))[key]
     except Exception:
-        return None, "no counter record for %s in profiles/r04_pmc.json" % key
+        return None, "no counter record for %s in profiles/r05_pmc.json" % key
     # like for like: the HIP-event launch time bench.py itself measured in the record's traced run (rocprofv3's own kernel-trace
     # average of that run, 1 % higher, is kept beside it and must agree: tests/test_bench_logic.py)
     ref = rec.get("hip_event_launch_ms_same_run") or rec.get("traced_avg_launch_ms") or 0.0
@@ -409,7 +409,7 @@ def main():
                          "fma_share_of_valu_insts": c["SQ_INSTS_VALU_FMA_F64"] / c["SQ_INSTS_VALU"] if "SQ_INSTS_VALU" in c else None,
                          "wave_time_waiting": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"] if "SQ_WAVE_CYCLES" in c else None,
                          "clock_ghz_under_load": cycles / (pmc_ms * 1e-3) / 1e9,
-                         "note": "from profiles/r04_pmc.json (separate --pmc passes on this binary); all 64 lanes counted"}
+                         "note": "from profiles/r05_pmc.json (separate --pmc passes on this binary); all 64 lanes counted"}
         out = {
             "metric": "MPC horizon-steps/sec across batch (3-level transmon, T=40)" if args.config == 3
                       else "MPC horizon-steps/sec across batch (config %d)" % args.config,
@@ -448,7 +448,7 @@ def main():
                                  "note": "compulsory bytes of the persistent launch (models, states and guesses once per run)"},
                          "traffic_note": (why + (" (N = %d ranks: the record is keyed by the per-GPU batch and was taken on one GPU "
                                                           "alone; frac above does not depend on it)" % joined if joined > 1 else "")) if why
-                                         else "FETCH_SIZE/WRITE_SIZE of profiles/r04_pmc.json, taken on this binary (launch time "
+                                         else "FETCH_SIZE/WRITE_SIZE of profiles/r05_pmc.json, taken on this binary (launch time "
                                                 "within 3 %): L2-miss bytes per launch, mostly served by the Infinity Cache"},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -50,12 +50,12 @@ def test_counter_records_are_refused_when_stale(tmp_path, monkeypatch):
 
 
 def test_committed_counter_records_cover_every_baseline_config():
-    recs = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc.json")))
+    recs = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc.json")))
     # (d = 2, 3 run their backward sweep on matrix-core tiles: key suffix _tile, MFMA instructions counted; d = 4, the complex path,
     #  and the DPP sweeps kept for comparison execute none; the exact mode at d = 3 runs its pinned sweep on tiles)
     for key, tile in (("config2_B8192_real_clip_tile", True), ("config3_B65536_real_clip_tile", True), ("config3_B65536_real_clip", False),
                       ("config3_B65536_complex_clip", False), ("config3_B65536_real_exact_tile", True), ("config4_B65536_real_clip", False),
-                      ("config5_B131072_real_clip_tile", True)):
+                      ("config4_B65536_real_clip_sg", False), ("config5_B131072_real_clip_tile", True)):
         r = recs[key]
         assert r["traced_avg_launch_ms"] > 0 and r["counters"]["SQ_INSTS_VALU_FMA_F64"] > 0
         assert (r["counters"]["SQ_INSTS_VALU_MFMA_MOPS_F64"] > 0) == tile
@@ -68,6 +68,9 @@ def test_committed_counter_records_cover_every_baseline_config():
     assert 40 <= per_index <= 48
     assert t["counters"]["SQ_INSTS_VALU"] < 0.65 * d["counters"]["SQ_INSTS_VALU"]
     assert t["traced_avg_launch_ms"] < 0.95 * d["traced_avg_launch_ms"]
+    # d = 4: the shared-generator kernel (two wavefronts per SIMD) against the per-member-model kernel of the same configuration
+    g, m = recs["config4_B65536_real_clip_sg"], recs["config4_B65536_real_clip"]
+    assert g["counters"]["SQ_WAVES"] == 2 * m["counters"]["SQ_WAVES"] and g["traced_avg_launch_ms"] < 0.95 * m["traced_avg_launch_ms"]
 
 
 def test_usable_cores_is_positive_and_bounded():

@@ -13,4 +13,6 @@ for args in "--config 3" "--config 3 --complex" "--config 3 --exact-qp" "--confi
 done
 # the DPP sweeps on the headline configuration, beside the tile sweep (M4Q_NO_TILE=1)
 M4Q_NO_TILE=1 timeout -k 10 900 python3 tools/pmc_collect.py --tag $tag --config 3 > gpurun_out/$tag/pmc_collect_config3_notile.log 2>&1; echo "pmc config 3 (DPP sweeps) rc=$?"
+# config 4 on per-member models, beside its shared-generator kernel (M4Q_NO_SG=1)
+M4Q_NO_SG=1 timeout -k 10 900 python3 tools/pmc_collect.py --tag $tag --config 4 > gpurun_out/$tag/pmc_collect_config4_nosg.log 2>&1; echo "pmc config 4 (per-member models) rc=$?"
 rm -rf gpurun_out/$tag/pmc_tmp_* gpurun_out/$tag/trace_tmp

@@ -19,7 +19,8 @@ ap.add_argument("--batch", type=int, default=16384)
 a = ap.parse_args()
 MODES = [("config3 real (tile sweep: default)", 3, {}), ("config3 complex", 3, {"force_complex": True}), ("config3 exact real (pinned sweep on tiles: default)", 3, {"exact_qp": True}),
          ("config3 exact real, DPP sweeps", 3, {"exact_qp": True, "tile": False}),
-         ("config3 exact complex", 3, {"exact_qp": True, "force_complex": True}), ("config4 real", 4, {}),
+         ("config3 exact complex", 3, {"exact_qp": True, "force_complex": True}), ("config4 real (shared generators: default)", 4, {}),
+         ("config4 real, per-member models", 4, {"shared_generators": False}),
          ("config4 complex", 4, {"force_complex": True}), ("config2 real", 2, {}), ("config5 real (T=80)", 5, {}),
          ("config3 real, 9 coordinates", 3, {"traceless": False}), ("config3 real, DPP sweeps", 3, {"tile": False}),
          ("config4 exact real", 4, {"exact_qp": True}), ("config2 exact real", 2, {"exact_qp": True})]
