@@ -1313,13 +1313,15 @@ def test_properties_at_full_baseline_size(cfg, batch):
 
 
 @pytest.mark.parametrize("kw", [{}, {"tile": False}, {"exact_qp": True}, {"exact_qp": True, "tile": False}, {"force_complex": True},
-                                {"traceless": False}])
+                                {"traceless": False}, {"config": 4}, {"config": 4, "shared_generators": False}])
 def test_repeated_launches_are_bit_identical(kw):
     """Rows pull their work from a device-wide queue, heads and tails of a run may land on different workgroups, and in the
     exact mode a solve spans a varying number of passes: none of that may reach the numbers.  Four launches of the same
     4,096-member problem must agree bit for bit (a soak of 116 full-size launches over all modes did)."""
     B = 4096
-    p = configs.build(3, batch=B, host_models=False)
+    kw = dict(kw)
+    cfg = kw.pop("config", 3)               # (config 4: the shared-generator kernel of d = 4 and the per-member-model kernel beside it)
+    p = configs.build(cfg, batch=B, host_models=False)
     n, m, T, ns = p["dim_x"], p["dim_u"], p["horizon"], p["n_steps"]
     sess = m4q.EnsembleSession(B, n, m, p["order"], T, ns, p["dt"], p["sat"], p["du"], model_per_instance=True,
                                target_cols=ns + T + 1, **kw)
@@ -1346,9 +1348,10 @@ def test_repeated_launches_are_bit_identical(kw):
     h = hashlib.sha256()
     for key in ("xs", "us", "qp_solves"):
         h.update(np.ascontiguousarray(first[key]).tobytes())
-    name = "config3_B4096_" + ("exact" if kw.get("exact_qp") else "clip") + (
+    name = "config%d_B4096_" % cfg + ("exact" if kw.get("exact_qp") else "clip") + (
         "_complex" if kw.get("force_complex") else "_real9" if kw.get("traceless") is False else
-        "_real" if kw.get("tile") is False else "_tile")      # ({}: the default - backward / pinned sweep on tiles)
+        "_real" if kw.get("tile") is False or kw.get("shared_generators") is False else
+        "_sg" if cfg == 4 else "_tile")                       # ({}: the default - backward / pinned sweep on tiles; d = 4: shared generators)
     store = os.environ.get("M4Q_STORE_CHECKSUMS")
     if store:
         have = json.load(open(store)) if os.path.exists(store) else {}
