@@ -31,6 +31,9 @@
 #ifndef M4Q_TCF
 #define M4Q_TCF(n) true               // constant-target instantiation of the rollout as well (xbar loaded once): config 3 35.77 -> 35.52 ms
 #endif
+#ifndef M4Q_SG_VFORM
+#define M4Q_SG_VFORM 1              // shared-generator rollout: the step as one product of the row [A | N_1 .. N_m] (63.3 -> 62.5 ms at config 4)
+#endif
 #ifndef M4Q_STORE_ALL
 // n >= 15: one wavefront per SIMD with 512 registers - loop-invariant operands of the exact mode's passes stay in registers
 #ifndef M4Q_N15_HOIST
@@ -1208,8 +1211,12 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
   auto step = [&](int t, const Ops& cur, Ops& nxt) __attribute__((always_inline)) {
     M4Q_NO_HOIST();
     nxt = load(t + 1 < T ? t + 1 : t);
+    // (SGV, shared generators: the step as ONE product of the row [A | N_1 .. N_m] read from LDS once,
+    //  x+ = A_i x + sum_k N_k (u~g_k x + (u~_k - u~g_k) xg) with u~ = s u - no row of A_t is built: NU NX FMAs per index fewer)
+    constexpr bool SGV = M4Q_SG_VFORM && fused_kind<Prov>::sg;
     S ax, Brow[NU], dlt;
-    if constexpr (HOIST) prov.rows(mregs, cur.lin, x, ax, Brow, dlt);
+    if constexpr (SGV) { (void)ax; (void)Brow; (void)dlt; }
+    else if constexpr (HOIST) prov.rows(mregs, cur.lin, x, ax, Brow, dlt);
     else prov.rows(cur.lin, x, ax, Brow, dlt);
     const S dx = csub(x, cur.xb);
     double u[NU];
@@ -1226,9 +1233,30 @@ __device__ __forceinline__ double rollout_forward(const Prov& prov, int T, S x0,
       u[k] = uk;
       if (t == 0) u_first[k] = uk;
     }
-    S xn = ref ? ax : cadd(ax, dlt);
+    S xn;
+    if constexpr (SGV) {
+      {
+        S row[NX];
 #pragma unroll
-    for (int k = 0; k < NU; ++k) cmac_r(xn, Brow[k], u[k]);
+        for (int k = 0; k < NX; ++k) row[k] = prov.el(0, j, k);
+        xn = dot_lane_index<false, false, NX>(x, row);
+      }
+#pragma unroll
+      for (int p = 0; p < NU; ++p) {
+        const double ugp = cur.lin.u[p];                       // (already scaled by the member's s_p)
+        const double dup = ref ? u[p] * prov.sc[p] : fma(u[p], prov.sc[p], -ugp);
+        S v = cscale(cur.lin.xg, dup);
+        cmac_r(v, x, ugp);
+        S row[NX];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) row[k] = prov.el(1 + p, j, k);
+        xn = dot_lane_index<false, false, NX>(v, row, xn);
+      }
+    } else {
+      xn = ref ? ax : cadd(ax, dlt);
+#pragma unroll
+      for (int k = 0; k < NU; ++k) cmac_r(xn, Brow[k], u[k]);
+    }
     if constexpr (WANT_COST) {
       const S* Rt = cost.r(t);
       const S e = ref ? xn : dx;

@@ -3,7 +3,7 @@
 #   tools/phase_per_pass.sh <lib> [ENV=VAL ...]     -> ns per pass for backward / forward and the launch time
 lib=$1; shift
 for kv in "$@"; do export "$kv"; done
-M4Q_LIB=$lib M4Q_PHASE_TRACE=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | python3 -c "
+M4Q_LIB=$lib M4Q_PHASE_TRACE=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline $M4Q_BENCH_ARGS 2>&1 | python3 -c "
 import sys, json, re
 t = {}; ms = None
 for line in sys.stdin:
