@@ -1693,6 +1693,36 @@ def test_shared_generator_path_selection_and_agreement():
     assert np.array_equal(r_sg["qp_solves"][idx], solves)
     assert np.all(np.abs(r_sg["us"][idx] - us).max(axis=(0, 1)) <= 1e-9 + 100 * eu)
     assert np.all(np.abs(r_sg["xs"][idx] - xs).max(axis=(0, 1))[1:] <= 1e-9 + 100 * ex[1:])
+    # the other code paths of the shared-generator kernel, each against the per-member-model kernel on the same device-built models
+    # (first MPC step to 1e-10, solve counts, the run within the loop's own sensitivity): measure_freq = 2 (the model closes the loop
+    # on the unmeasured steps: the provider's scaled controls in DMDc.predict's arithmetic), a target that moves over the window (the
+    # sweep's general form instead of its constant-target form), a batch that does not fill its last wavefront
+    def pair(Bn, mutate=None, **kw):
+        q = {k: (v[:Bn] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in p.items()}
+        if mutate:
+            mutate(q)
+        out = []
+        for sg in (None, False):
+            sess = _session(q, Bn, shared_generators=sg, **kw)
+            try:
+                sess.build_models(q["dt"], q["generators"], q["scales"])
+                sess.load_problem(None, q["x0"], q["X_targ"], q["U_targ"], q["Q"], q["R"], q["Qf"], q["plant_op0"], q["plant_ops"])
+                sess.run(0, q["n_steps"])
+                out.append((sess.path_detail(), sess.results()))
+            finally:
+                sess.close()
+        (da, a), (db, b) = out
+        assert da == "traceless-sg" and db == "traceless", (da, db)
+        assert np.array_equal(a["qp_solves"], b["qp_solves"]) and np.all(a["exit_codes"] == 0)
+        assert rel(a["us"][:, 0], b["us"][:, 0]) <= 1e-10 and rel(a["xs"][:, 1], b["xs"][:, 1]) <= 1e-10
+        return np.abs(a["us"] - b["us"]).max()
+
+    def ramped(q):                     # a target that moves between two unit-trace states: still traceless, no longer constant
+        lam = np.linspace(0.0, 0.05, q["X_targ"].shape[1])[None, :]
+        q["X_targ"] = (1 - lam) * q["X_targ"] + lam * q["x0"][0][:, None]
+    assert pair(16, measure_freq=2) <= 1e-6 * p["sat"]
+    assert pair(16, ramped) <= 1e-6 * p["sat"]
+    assert pair(5) <= 1e-6 * p["sat"]
     q3 = configs.build(3, batch=4, horizon=8, n_steps=3)
     s3 = _session(q3, 4)
     try:
