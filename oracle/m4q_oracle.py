@@ -12,7 +12,11 @@ Parity status (see tests/golden/make_golden.py and tests/test_oracle_golden.py):
   * ``discretize_homogeneous`` is also pinned by the reference's known-answer test
     (tests/test_mpc4quantum.py:147-188, order 1 / dt 1  =>  [I + A | N_1 | ...]);
   * the ``Delta``/``X_bm[t+1]`` extension of the Riccati solve (mode "qp") is pinned by an
-    independent dense KKT solve of the equality-constrained QP stated at optimize.py:27-41,54;
+    independent dense KKT solve of the equality-constrained QP stated at optimize.py:27-41,54 -
+    at small T and at the headline configuration's own T = 40 with Delta != 0, a ramped state
+    target and a control target (tests/test_oracle_golden.py);
+  * the driver (``mpc``: SQP loop, line search, shift, exit codes, clock) is pinned against the
+    reference's own mpc.py run around its own lqr.py (tests/golden/mpc_loop*.npz);
   * the live cvxpy/OSQP arithmetic (optimize.py:58-59) and qutip.mesolve (experiment.py:209)
     are third-party and absent: those two boundaries are PARITY UNPINNED.  The plant is restated
     as the exact propagator of the ODE at experiment.py:190-191,208 under a held control.
