@@ -233,13 +233,23 @@ class _HeldControl:
 
 def open_session(x0, models, dim_u, order, X_targ, U_targ, clock, plant_op0, plant_ops, Q, R, Qf, sat, du=None,
                  max_iter=100, warm_start=True, qp_flags=None, plant_kind=_lib.PLANT_HAMILTONIAN, device=-1,
-                 force_complex=False, exact_qp=False, traceless=True, tile=None):
-    """An EnsembleSession loaded with mpc_batch's arguments (everything resident in HBM, nothing run yet)."""
+                 force_complex=False, exact_qp=False, traceless=True, tile=None, generators=None, scales=None,
+                 shared_generators=None):
+    """An EnsembleSession loaded with mpc_batch's arguments (everything resident in HBM, nothing run yet).
+    models = None with generators [1+m, n, n] (or [B, 1+m, n, n]) and optional scales [B, 1+m]: the members' models are built on the
+    device (discretize_homogeneous of the scaled generators, vectorize.py:8-49), and a set of SHARED generators at order 1 lets the
+    closed loop run on them directly where that kernel exists (d = 4; EnsembleSession(shared_generators=...))."""
     x0 = np.ascontiguousarray(x0, dtype=np.complex128)
     Bn, n = x0.shape
-    models = np.asarray(models, dtype=np.complex128)
-    if models.ndim == 2:
-        models = models[None]
+    if models is None:
+        if generators is None:
+            raise TypeError("models is None: pass generators (and scales) to have the models built on the device")
+        per_model = True
+    else:
+        models = np.asarray(models, dtype=np.complex128)
+        if models.ndim == 2:
+            models = models[None]
+        per_model = models.shape[0] > 1
     op0 = np.asarray(plant_op0, dtype=np.complex128)
     ops = np.asarray(plant_ops, dtype=np.complex128)
     if op0.ndim == 2:
@@ -255,9 +265,11 @@ def open_session(x0, models, dim_u, order, X_targ, U_targ, clock, plant_op0, pla
     T, ns = clock.horizon, clock.n_steps
     cols = min(X_targ.shape[-1], ns + T + 1)
     sess = EnsembleSession(Bn, n, dim_u, order, T, ns, clock.dt, sat, du, max_iter, warm_start, qp_flags, plant_kind,
-                           models.shape[0] > 1, per_plant, per_targ, cols, device=device, force_complex=force_complex, traceless=traceless, tile=tile,
-                           measure_freq=getattr(clock, "measure_freq", 1), exact_qp=exact_qp)
+                           per_model, per_plant, per_targ, cols, device=device, force_complex=force_complex, traceless=traceless, tile=tile,
+                           measure_freq=getattr(clock, "measure_freq", 1), exact_qp=exact_qp, shared_generators=shared_generators)
     try:
+        if models is None:
+            sess.build_models(clock.dt, generators, scales)
         sess.load_problem(models, x0, X_targ, U_targ, Q, R, Qf, op0, ops)
     except Exception:
         sess.close()
@@ -267,13 +279,15 @@ def open_session(x0, models, dim_u, order, X_targ, U_targ, clock, plant_op0, pla
 
 def mpc_batch(x0, models, dim_u, order, X_targ, U_targ, clock, plant_op0, plant_ops, Q, R, Qf, sat, du=None,
               max_iter=100, warm_start=True, qp_flags=None, plant_kind=_lib.PLANT_HAMILTONIAN, device=-1,
-              force_complex=False, exact_qp=False, traceless=True, tile=None):
+              force_complex=False, exact_qp=False, traceless=True, tile=None, generators=None, scales=None, shared_generators=None):
     """B independent closed loops in one launch.
-    x0 [B, n]; models [B|1, n, n(1+P)]; X_targ (n, cols) / U_targ (m, cols) shared (or [B, ...] each);
+    x0 [B, n]; models [B|1, n, n(1+P)] (or None with generators / scales: built on the device, see open_session);
+    X_targ (n, cols) / U_targ (m, cols) shared (or [B, ...] each);
     plant_op0 [B|1, k, k], plant_ops [B|1, m, k, k].  Returns a dict: xs [B, n, n_steps+1], us [B, m, n_steps]
     (entries beyond steps_done are not meaningful), exit_codes, steps_done, qp_solves [B, n_steps]."""
     sess = open_session(x0, models, dim_u, order, X_targ, U_targ, clock, plant_op0, plant_ops, Q, R, Qf, sat, du, max_iter,
-                        warm_start, qp_flags, plant_kind, device, force_complex, exact_qp, traceless, tile)
+                        warm_start, qp_flags, plant_kind, device, force_complex, exact_qp, traceless, tile, generators, scales,
+                        shared_generators)
     try:
         sess.run(0, clock.n_steps)
         res = sess.results()

@@ -1723,6 +1723,11 @@ def test_shared_generator_path_selection_and_agreement():
     assert pair(16, measure_freq=2) <= 1e-6 * p["sat"]
     assert pair(16, ramped) <= 1e-6 * p["sat"]
     assert pair(5) <= 1e-6 * p["sat"]
+    # the ensemble entry point with generators instead of models: same path, same numbers
+    clock = m4q.StepClock(p["dt"], p["horizon"], p["n_steps"])
+    res = m4q.mpc_batch(p["x0"], None, p["dim_u"], p["order"], p["X_targ"], p["U_targ"], clock, p["plant_op0"], p["plant_ops"], p["Q"],
+                        p["R"], p["Qf"], p["sat"], p["du"], generators=p["generators"], scales=p["scales"])
+    assert res["path_detail"] == "traceless-sg" and np.array_equal(res["us"], r_sg["us"]) and np.array_equal(res["xs"], r_sg["xs"])
     q3 = configs.build(3, batch=4, horizon=8, n_steps=3)
     s3 = _session(q3, 4)
     try:
