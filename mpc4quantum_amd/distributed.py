@@ -444,12 +444,25 @@ def mpc_batch_sharded(x0, models, dim_u, order, X_targ, U_targ, clock, plant_op0
     if transport.on_device and min(counts) == 0:
         # decided on data every rank has, so every rank raises - none is left waiting inside the collective
         raise ValueError("more ranks (%d) than ensemble members (%d)" % (world, B))
-    models = np.asarray(models)
-    if models.ndim == 2:
-        models = models[None]
+    if models is None:
+        # models built on the device from generators (and per-member scales): every rank builds its own block's
+        # (mpc.open_session: shared generators at order 1 then run the shared-generator kernel where it exists)
+        if kw.get("generators") is None:
+            raise TypeError("models is None: pass generators (and scales)")
+        kw = dict(kw)
+        g = np.asarray(kw["generators"])
+        kw["generators"] = g[lo:hi] if g.ndim == 4 and g.shape[0] == B else g
+        if kw.get("scales") is not None:
+            kw["scales"] = np.asarray(kw["scales"])[lo:hi]
+        models_blk = None
+    else:
+        models = np.asarray(models)
+        if models.ndim == 2:
+            models = models[None]
+        models_blk = _take(models, lo, hi, B)
     op0 = np.asarray(plant_op0)
     ops = np.asarray(plant_ops)
-    args = (x0[lo:hi], _take(models, lo, hi, B), dim_u, order,
+    args = (x0[lo:hi], models_blk, dim_u, order,
             X_targ if np.ndim(X_targ) == 2 else _take(X_targ, lo, hi, B),
             U_targ if np.ndim(U_targ) == 2 else _take(U_targ, lo, hi, B), clock,
             _take(op0, lo, hi, B) if op0.ndim == 3 else op0, _take(ops, lo, hi, B) if ops.ndim == 4 else ops,

@@ -1765,6 +1765,16 @@ for final_only in (False, True):
     assert np.array_equal(got["xs"], xs), ("xs", final_only)
     for k in ("us", "exit_codes", "steps_done", "qp_solves"):
         assert np.array_equal(got[k], ref[k]), (k, final_only)
+# an ensemble given by shared generators and per-member scales (d = 4: the shared-generator kernel), models built by every rank
+q = configs.build(4, batch=9, horizon=10, n_steps=4)
+clk = lambda: m4q.StepClock(q["dt"], q["horizon"], q["n_steps"])
+gargs = lambda: (q["x0"], None, q["dim_u"], q["order"], q["X_targ"], q["U_targ"], clk(), q["plant_op0"], q["plant_ops"], q["Q"], q["R"],
+                 q["Qf"], q["sat"], q["du"])
+ref = m4q.mpc_batch(*gargs(), generators=q["generators"], scales=q["scales"])
+assert ref["path_detail"] == "traceless-sg"
+got = mpc_batch_sharded(*gargs(), generators=q["generators"], scales=q["scales"])
+for k in ("xs", "us", "exit_codes", "steps_done", "qp_solves"):
+    assert np.array_equal(got[k], ref[k]), ("generators", k)
 comm = RcclComm.from_env()
 assert comm.allreduce([1.5, 2.0], "sum").tolist() == [1.5, 2.0] and comm.allreduce([3.0], "max").tolist() == [3.0]
 comm.barrier()
