@@ -34,6 +34,9 @@ __device__ __forceinline__ double to_sgpr(double x) {
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
 }
 
+#ifndef M4Q_TILE_CBLK
+#define M4Q_TILE_CBLK 1               // the affine column c of a block's four indices formed once per block (bit-identical; config 3 29.8 -> 29.3 ms)
+#endif
 // PINNED: the sweep of the exact box-QP iteration (riccati_backward<PINNED> of m4q_mpc.h, same algebra): controls of the working
 // set `stat` ([T][NU]: 0 free, +1 / -1 pinned at the upper / lower bound) are constants of their stage; the stored row of a pinned
 // control is the affine form of its multiplier.
@@ -158,7 +161,7 @@ struct TileBackwardB {
 
     // one horizon index; ug / ub: its controls and control targets, b: rowrep(N_s x_g), all replicated over the member's lanes
     auto step = [&](int t, const double (&ug)[NU], const double (&ub)[NU], const double (&b)[NU][NT],
-                    const double (&stv)[NU]) __attribute__((always_inline)) {
+                    const double (&stv)[NU], const double (&cin)[NT]) __attribute__((always_inline)) {
       double At[NT][NT], c[NT], W[NT], Y[NT], H[NT];
 #pragma unroll
       for (int I = 0; I < NT; ++I)
@@ -171,11 +174,16 @@ struct TileBackwardB {
         }
 #pragma unroll
       for (int K = 0; K < NT; ++K) {
-        double a = tt[0][K];
+        double a;
+        if constexpr (M4Q_TILE_CBLK) {
+          a = cin[K];                                                           // (formed for the block's four indices at once: block())
+        } else {
+          a = tt[0][K];
 #pragma unroll
-        for (int p = 0; p < NP; ++p) a = fma(ug[p], tt[1 + p][K], a);
+          for (int p = 0; p < NP; ++p) a = fma(ug[p], tt[1 + p][K], a);
 #pragma unroll
-        for (int s = 0; s < NU; ++s) a = fma(b[s][K], ub[s] - ug[s], a);        // + B ubar + Delta, Delta = -B u_g
+          for (int s = 0; s < NU; ++s) a = fma(b[s][K], ub[s] - ug[s], a);      // + B ubar + Delta, Delta = -B u_g
+        }
         c[K] = a;
         double w = isq[NU] ? a : 0.0;                                           // W = [B | c | 0]
 #pragma unroll
@@ -376,19 +384,36 @@ struct TileBackwardB {
           for (int K = 0; K < NT; ++K) acc = mm(NpT[s][K][I], cur.xt[K], acc);   // [r][q] = (N_s x_g(tb - q))[4I + r]
           BT[s][I] = acc;
         }
+      // the affine column c = A xbar - xbar+ + sum_p u_p N_p xbar + B (ubar - u_g) of the block's four indices as ONE tile per K (lane
+      // q holds time tb - q, as the operands do): the same fused multiply-adds in the same order as per index - bit-identical - issued
+      // once per block instead of once per index (M4Q_TILE_CBLK)
+      double CT[NT];
+      if constexpr (M4Q_TILE_CBLK) {
+#pragma unroll
+        for (int K = 0; K < NT; ++K) {
+          double a = tt[0][K];
+#pragma unroll
+          for (int p = 0; p < NP; ++p) a = fma(cur.ug[p], tt[1 + p][K], a);
+#pragma unroll
+          for (int s = 0; s < NU; ++s) a = fma(BT[s][K], cur.ub[s] - cur.ug[s], a);
+          CT[K] = a;
+        }
+      }
       static_for<0, 4>([&](auto jj) {
         constexpr int j = decltype(jj)::value;
         if (j < cnt) {
-          double ug[NU], ub[NU], b[NU][NT], stv[NU];
+          double ug[NU], ub[NU], b[NU][NT], stv[NU], cin[NT];
 #pragma unroll
           for (int s = 0; s < NU; ++s) {
             ug[s] = quad_bcast<j>(cur.ug[s]);
-            ub[s] = quad_bcast<j>(cur.ub[s]);
+            ub[s] = (PINNED || !M4Q_TILE_CBLK) ? quad_bcast<j>(cur.ub[s]) : 0.0;
             stv[s] = PINNED ? quad_bcast<j>(cur.st[s]) : 0.0;
 #pragma unroll
             for (int I = 0; I < NT; ++I) b[s][I] = quad_bcast<j>(BT[s][I]);
           }
-          step(tb - j, ug, ub, b, stv);
+#pragma unroll
+          for (int K = 0; K < NT; ++K) cin[K] = M4Q_TILE_CBLK ? quad_bcast<j>(CT[K]) : 0.0;
+          step(tb - j, ug, ub, b, stv, cin);
         }
       });
     };
