@@ -34,6 +34,9 @@ __device__ __forceinline__ double to_sgpr(double x) {
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
 }
 
+#ifndef M4Q_TILE_GB_BATCH
+#define M4Q_TILE_GB_BATCH 1
+#endif
 #ifndef M4Q_TILE_CBLK
 #define M4Q_TILE_CBLK 1               // the affine column c of a block's four indices formed once per block (bit-identical; config 3 29.8 -> 29.3 ms)
 #endif
@@ -211,12 +214,33 @@ struct TileBackwardB {
       wave_sync();
       cplx gm[NU][NU], ginv[NU][NU];
       double h[NU];
+#if M4Q_TILE_GB_BATCH
+      {
+        // (all reads of the G / h tile issued before the first use: gb is volatile, and read-add-read-add made each of the
+        //  NU (NU + 3) / 2 reads its own LDS round trip on the index's dependent chain)
+        double gv[NU][NU], hv[NU];
+#pragma unroll
+        for (int s = 0; s < NU; ++s) {
+#pragma unroll
+          for (int l = s; l < NU; ++l) gv[s][l] = gb[s * 4 + l];
+          hv[s] = gb[s * 4 + NU];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < NU; ++s) {
+#pragma unroll
+          for (int l = s; l < NU; ++l) gm[s][l] = mk(gv[s][l] + Rm[s][l], 0.0);
+          h[s] = hv[s];
+        }
+      }
+#else
 #pragma unroll
       for (int s = 0; s < NU; ++s) {
 #pragma unroll
         for (int l = s; l < NU; ++l) gm[s][l] = mk(gb[s * 4 + l] + Rm[s][l], 0.0);
         h[s] = gb[s * 4 + NU];
       }
+#endif
       wave_sync();
       bool fix[NU];
       double dufix[NU], hraw[NU], Gf[NU][NU];
